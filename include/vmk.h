@@ -1,0 +1,289 @@
+/*
+ * vmk.h — C-ABI of the MI355X-native megakernel path-tracing backend ("vmk") that sits behind
+ * Vision's Integrator/Pipeline plugin surface.
+ *
+ * Everything below Vision's `Integrator::render()` and the scene-upload half of `Pipeline::prepare()`
+ * is replaced by this library.  Reference interfaces each entry point stands in for (paths relative to
+ * the Vision source tree, file:line):
+ *
+ *   vmk_create / vmk_destroy        RHIContext::create_device + Pipeline ctor   src/apps/vision-gui/application.h:64-69,
+ *                                                                               src/base/mgr/pipeline.cpp:13-31
+ *   vmk_upload_scene                Scene::prepare + Geometry::update_instances/upload + ImagePool::prepare +
+ *                                   upload_bindless_array                       src/base/mgr/scene.cpp:79-91,
+ *                                                                               src/base/mgr/geometry.cpp:20-34,64-71,
+ *                                                                               src/base/mgr/image_pool.cpp:48-54
+ *   vmk_build_accel                 Geometry::build_accel (OptiX BLAS/TLAS)     src/base/mgr/geometry.cpp:36-53
+ *   vmk_set_render_params           Sensor::update_device_data, IlluminationIntegrator ctor params,
+ *                                   FrameBuffer ctor                            src/base/sensor/sensor.cpp:141-145,
+ *                                                                               src/base/integral/integrator.cpp:59-66,
+ *                                                                               src/base/sensor/frame_buffer.cpp:15-26
+ *   vmk_render_batch                PathTracingIntegrator::render() x frame_count (rt_geom ray-gen + path_tracing +
+ *                                   accumulate, fused)                          src/render_core/integrator/pt.cpp:96-116,
+ *                                                                               src/base/integral/integrator.cpp:82-107,
+ *                                                                               src/base/sensor/frame_buffer.cpp:117-126,156-219
+ *   vmk_reset_accum                 Integrator::invalidation()                  src/base/integral/integrator.cpp:13-18
+ *   vmk_tonemap                     FrameBuffer tone_mapping + gamma kernels,
+ *                                   Pipeline::final_picture                     src/base/sensor/frame_buffer.cpp:135-154,
+ *                                                                               src/base/mgr/pipeline.cpp:337-354
+ *   vmk_download_accum              FrameBuffer download                        src/base/sensor/frame_buffer.cpp:424-427,467-469
+ *   vmk_last_error                  OC_ERROR logging (reference has no error returns; src/base/node.h:116)
+ *
+ * Conventions: plain C, no C++/torch types.  Every function returns 0 on success and a negative
+ * vmk_status on failure; vmk_last_error(ctx) gives the message.  A ctx is bound to ONE GPU and is not
+ * thread-safe; drive one ctx per GPU (one process per GPU under torch.distributed).  The creator owns
+ * every handle; host tables passed to vmk_upload_scene are copied and may be freed afterwards.
+ * All matrices are column-major float[16]/float[9] like ocarina's float4x4 (m[col*4+row]).
+ */
+#ifndef VMK_H
+#define VMK_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMK_ABI_VERSION 1u
+#define VMK_INVALID 0xFFFFFFFFu
+
+typedef enum vmk_status {
+    VMK_OK = 0,
+    VMK_ERR_ARG = -1,        /* bad argument / inconsistent table sizes */
+    VMK_ERR_HIP = -2,        /* a HIP runtime call failed               */
+    VMK_ERR_STATE = -3,      /* call order violated (e.g. render before build_accel) */
+    VMK_ERR_UNSUPPORTED = -4 /* scene uses a feature outside the hot-path scope */
+} vmk_status;
+
+/* ---- material / light vocabulary (Vision plugin type names, src/render_core/material, light) ---- */
+typedef enum vmk_material_type {
+    VMK_MAT_DIFFUSE = 0,    /* "diffuse"          diffuse.cpp:21-30   slots: color, sigma */
+    VMK_MAT_MIRROR = 1,     /* "mirror"           mirror.cpp:60-74    slots: color, roughness, anisotropic */
+    VMK_MAT_METAL = 2,      /* "metal"            metal.cpp:137-156   slots: eta, k, roughness, anisotropic */
+    VMK_MAT_GLASS = 3,      /* "glass"            glass.cpp:240-257   slots: color, ior, roughness, anisotropic */
+    VMK_MAT_SUBSTRATE = 4,  /* "substrate"        substrate.cpp:126-149 slots: color, spec, roughness, anisotropic */
+    VMK_MAT_PRINCIPLED = 5, /* "principled_bsdf"  principled_bsdf.cpp:352-461, 18 slots in declaration order */
+    VMK_MAT_MIX = 6         /* "mix"              mix.cpp:66-71       slot: frac; children child0/child1 */
+} vmk_material_type;
+
+enum { /* principled slot indices, principled_bsdf.cpp:235-256 */
+    VMK_P_COLOR = 0, VMK_P_METALLIC, VMK_P_IOR, VMK_P_ROUGHNESS, VMK_P_SPEC_TINT, VMK_P_ANISOTROPIC, VMK_P_OPACITY,
+    VMK_P_SHEEN_WEIGHT, VMK_P_SHEEN_ROUGHNESS, VMK_P_SHEEN_TINT, VMK_P_COAT_WEIGHT, VMK_P_COAT_ROUGHNESS,
+    VMK_P_COAT_IOR, VMK_P_COAT_TINT, VMK_P_SSS_WEIGHT, VMK_P_SSS_RADIUS, VMK_P_SSS_SCALE, VMK_P_TRANS_WEIGHT,
+    VMK_P_SLOT_COUNT
+};
+#define VMK_MAX_SLOTS 18
+
+#define VMK_MATF_REMAP_ROUGHNESS 1u /* desc["remapping_roughness"] (default true) */
+#define VMK_MATF_HAS_SIGMA 2u       /* diffuse: Oren-Nayar when "sigma" present (diffuse.cpp:24-27) */
+
+/* A material / light parameter slot (ShaderNodeSlot, src/base/shader_graph/shader_node.cpp:242-273).
+ * tex == VMK_INVALID : constant, value v[0..2] (scalar slots use v[0]).
+ * otherwise          : image node (render_core/shadernode/image.cpp:87-97): texel(uv) * v[0](=scale),
+ *                      low 16 bits = texture index, bits 16..21 = 3 x 2-bit channel swizzle (x,y,z sources). */
+typedef struct vmk_slot {
+    float v[3];
+    uint32_t tex;
+} vmk_slot;
+
+typedef struct vmk_material {
+    uint32_t type;  /* vmk_material_type */
+    uint32_t flags; /* VMK_MATF_* */
+    uint32_t child0, child1; /* mix only: indices into materials[] (must be non-mix) */
+    vmk_slot slot[VMK_MAX_SLOTS];
+} vmk_material;
+
+typedef enum vmk_light_type {
+    VMK_LIGHT_AREA = 0,     /* "area"      render_core/light/area.cpp */
+    VMK_LIGHT_SPHERICAL = 1 /* "spherical" render_core/light/environments/spherical.cpp */
+} vmk_light_type;
+
+typedef struct vmk_light {
+    uint32_t type;
+    uint32_t inst_id;      /* area: emissive instance */
+    uint32_t two_sided;    /* area */
+    float scale;           /* Light::scale_ after color normalisation (light.cpp:19-24) */
+    vmk_slot color;        /* normalised colour (max component <= 1) or image */
+    uint32_t alias_offset; /* area: 1-D alias table over the instance's triangles (by area); env: marginal (rows) */
+    uint32_t alias_count;
+    float alias_integral;  /* AliasTable::integral_ = sum/size (alias.h:119) */
+    uint32_t cond_offset;  /* env: flat conditional tables, res.x entries per row (alias2d.cpp:56-66) */
+    uint32_t res_x, res_y; /* env: importance-map resolution */
+    float w2o[9];          /* env: 3x3 of w2o_  (spherical.cpp:36-44), column-major */
+    float o2w[9];          /* env: 3x3 of inverse(w2o_) as evaluated by the reference per sample (spherical.cpp:114) */
+    float world_diameter;  /* env: Scene::world_diameter() (scene.h:108-109) */
+} vmk_light;
+
+/* ---- geometry -------------------------------------------------------------------------------- */
+/* One record per triangle, instance order (instance i owns [tri_offset, tri_offset+tri_count)).
+ * Positions are WORLD space: p = o2w.apply_point(v.position) evaluated on the host with the same
+ * float arithmetic compute_surface_interaction uses per hit (geometry.cpp:94-96). 48 B = S_tri. */
+typedef struct vmk_tri_pos {
+    float p0[3], p1[3], p2[3];
+    uint32_t inst; /* instance index */
+    uint32_t prim; /* triangle index inside the instance's mesh (TriangleHit::prim_id) */
+    uint32_t pad;
+} vmk_tri_pos;
+
+/* Shading attributes of the same triangle: OBJECT-space vertex normals (transformed after
+ * interpolation like geometry.cpp:128-133) and texture coordinates. 64 B. */
+typedef struct vmk_tri_attr {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float pad;
+} vmk_tri_attr;
+
+typedef struct vmk_instance { /* InstanceData, src/base/shape.h:21-33 */
+    uint32_t mat_id;   /* index into materials[] or VMK_INVALID */
+    uint32_t light_id; /* index into lights[] or VMK_INVALID */
+    uint32_t tri_offset, tri_count;
+    float n2w[9];      /* normal matrix: transpose(inverse(o2w 3x3)), column-major (Transform::apply_normal) */
+    float o2w[16];     /* kept for reference / debugging */
+} vmk_instance;
+
+/* ---- textures ----------------------------------------------------------------------------------- */
+typedef enum vmk_tex_format { VMK_TEX_RGBA8_SRGB = 0, VMK_TEX_RGBA8_LINEAR = 1, VMK_TEX_RGBA32F = 2 } vmk_tex_format;
+typedef struct vmk_texture {
+    uint64_t offset; /* byte offset into tex_data (16-byte aligned) */
+    uint32_t width, height;
+    uint32_t format; /* vmk_tex_format */
+    uint32_t channels; /* channel count of the source image (ImageNode::channel_num) */
+} vmk_texture;
+
+/* ---- precomputed albedo tables (base/scattering/precomputed_table.h, ltc_sheen_table.h) -------------- */
+#define VMK_LUT_RES 32
+typedef struct vmk_luts {
+    const float *pure_reflection; /* [32*32]      PureReflectionLobe::lut   (x=alpha, y=cos) */
+    const float *dielectric;      /* [32^3 * 2]   DielectricLobe::lut       float2 */
+    const float *dielectric_inv;  /* [32^3 * 2]   DielectricLobeInv::lut    float2 */
+    const float *specular;        /* [32^3]       SpecularLobe::lut */
+    const float *coat;            /* [32^3]       CoatLobe::lut */
+    const float *sheen_approx;    /* [32*32*4]    SheenLTC::Approximate (may be NULL -> sheen disabled) */
+    const float *sheen_volume;    /* [32*32*4]    SheenLTC::Volume */
+} vmk_luts;
+
+/* ---- whole scene ------------------------------------------------------------------------------------ */
+typedef struct vmk_scene {
+    uint32_t abi_version;
+    uint32_t n_tris, n_instances, n_materials, n_lights, n_textures, n_alias;
+    const vmk_tri_pos *tri_pos;
+    const vmk_tri_attr *tri_attr;
+    const vmk_instance *instances;
+    const vmk_material *materials;
+    const vmk_light *lights;     /* order = LightSampler order after tidy_up (lightsampler.cpp:64-74) */
+    const vmk_texture *textures;
+    const uint8_t *tex_data;
+    uint64_t tex_bytes;
+    const float *alias_prob;     /* AliasEntry::prob   (alias.h:13-16) */
+    const uint32_t *alias_idx;   /* AliasEntry::alias */
+    const float *alias_func;     /* AliasTable::func_ */
+    uint32_t env_light;          /* index of the environment light in lights[] or VMK_INVALID */
+    float world_min[3], world_max[3];
+    vmk_luts luts;
+} vmk_scene;
+
+/* ---- camera / film / integrator ---------------------------------------------------------------------- */
+typedef enum vmk_filter_type { VMK_FILTER_BOX = 0, VMK_FILTER_TRIANGLE = 1, VMK_FILTER_TABLE = 2 } vmk_filter_type;
+#define VMK_FILTER_TABLE_SIZE 20 /* FilterSampler::table_size, fitted_curve.h:19 */
+
+typedef struct vmk_render_params {
+    uint32_t width, height;
+    /* Sensor (sensor.cpp:44-71,153-162; thin_lens.cpp:34-42) */
+    float c2w[16];              /* camera_to_world() */
+    float raster_to_sensor[16]; /* inverse(perspective) * raster_to_screen */
+    float lens_radius, focal_distance;
+    /* Filter (box.cpp:16-20, triangle.cpp:16-18, fitted_curve.h:76-113) */
+    uint32_t filter_type;
+    float filter_radius[2];
+    /* fitted-curve filters (gaussian/mitchell/sinc): alias-2D over |f| on a 20x20 grid */
+    float filter_marginal_prob[VMK_FILTER_TABLE_SIZE];
+    uint32_t filter_marginal_alias[VMK_FILTER_TABLE_SIZE];
+    float filter_marginal_func[VMK_FILTER_TABLE_SIZE];
+    float filter_marginal_integral;
+    float filter_cond_prob[VMK_FILTER_TABLE_SIZE * VMK_FILTER_TABLE_SIZE];
+    uint32_t filter_cond_alias[VMK_FILTER_TABLE_SIZE * VMK_FILTER_TABLE_SIZE];
+    float filter_cond_func[VMK_FILTER_TABLE_SIZE * VMK_FILTER_TABLE_SIZE];
+    /* IlluminationIntegrator (integrator.cpp:59-66) */
+    uint32_t max_depth, min_depth;
+    float rr_threshold;
+    uint32_t mis_mode; /* 0 both, 1 light, 2 bsdf (integrator.h:116-120) */
+    /* LightSampler (lightsampler.cpp:11-14) */
+    uint32_t env_separate;
+    float env_prob;
+    float ray_offset_factor; /* render_setting.ray_offset_factor (scene.cpp:33) */
+    /* FrameBuffer (frame_buffer.cpp:15-26) */
+    float exposure;
+    uint32_t tone_mapper; /* 0 linear, 1 aces, 2 reinhard (tonemapper/impl.cpp:16-45) */
+} vmk_render_params;
+
+/* Tile ownership for multi-GPU sharding: image cut into tile_size^2 tiles in row-major order, tile t is
+ * rendered by this ctx iff owner(t) == rank, owner(t) = bitrev-permuted t mod world. */
+typedef struct vmk_tiles {
+    uint32_t tile_size; /* pixels, power of two; 0 => whole image, single owner */
+    uint32_t rank, world;
+} vmk_tiles;
+
+typedef struct vmk_counters { /* cumulative since vmk_reset_counters */
+    uint64_t closest_rays;    /* trace_closest calls */
+    uint64_t shadow_rays;     /* trace_occlusion calls */
+    uint64_t nodes_visited;   /* BVH node records fetched */
+    uint64_t tris_tested;     /* triangle records fetched */
+    uint64_t paths;           /* camera samples started */
+    uint64_t surface_hits;    /* closest hits that were shaded */
+    uint64_t tex_fetches;     /* bilinear texture lookups (4 texels each) */
+} vmk_counters;
+
+typedef struct vmk_ctx vmk_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+int vmk_create(int device, vmk_ctx **out);
+void vmk_destroy(vmk_ctx *ctx);
+const char *vmk_last_error(const vmk_ctx *ctx); /* valid until the next call on ctx; ctx may be NULL */
+uint32_t vmk_abi_version(void);
+
+int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *scene);
+int vmk_build_accel(vmk_ctx *ctx); /* GPU LBVH: Morton codes -> radix sort -> Karras hierarchy -> refit */
+int vmk_set_render_params(vmk_ctx *ctx, const vmk_render_params *params);
+
+/* Film. fb == NULL: the ctx owns a width*height float4 accumulation buffer. Otherwise fb is a DEVICE
+ * pointer to width*height*4 floats owned by the caller (e.g. a torch tensor that is all-reduced). */
+int vmk_set_framebuffer(vmk_ctx *ctx, void *fb_device);
+int vmk_reset_accum(vmk_ctx *ctx);
+
+/* Render frames [frame_begin, frame_begin+frame_count) of the owned tiles, fused with accumulation:
+ * acc = lerp(1/(f+1), acc, L_f) per frame f in order (frame_buffer.cpp:117-126).  Asynchronous on the
+ * ctx stream; kernel_ms (optional) receives the HIP-event time of the launch and forces a sync. */
+int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, const vmk_tiles *tiles,
+                     float *kernel_ms);
+int vmk_synchronize(vmk_ctx *ctx);
+int vmk_download_accum(vmk_ctx *ctx, float *out_rgba /* width*height*4 */);
+/* exposure -> tone map -> (optional second tone map + sRGB, Pipeline::final_picture) -> host RGBA float */
+int vmk_tonemap(vmk_ctx *ctx, int final_picture, float *out_rgba);
+
+int vmk_get_counters(vmk_ctx *ctx, vmk_counters *out);
+int vmk_reset_counters(vmk_ctx *ctx);
+void *vmk_stream(vmk_ctx *ctx); /* hipStream_t the ctx launches on */
+
+/* ---- BVH introspection + traversal replay (SURVEY §8d traversal-only roofline) ------------------------ */
+typedef struct vmk_accel_info {
+    uint32_t n_nodes, n_leaves, node_bytes, tri_bytes;
+    float build_ms;
+} vmk_accel_info;
+int vmk_accel_info_get(vmk_ctx *ctx, vmk_accel_info *out);
+
+/* Trace n rays given as SoA device-resident copies of host arrays (origin xyz, dir xyz, tmax); writes
+ * hits as {inst, prim, bary.x, bary.y} (inst == VMK_INVALID on miss).  any_hit != 0: occlusion query,
+ * hit[i*4] = 1/0.  Returns kernel time of the traversal launch in *kernel_ms. */
+int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *dir_xyz, const float *tmax,
+                   int any_hit, uint32_t *hit_out /* n*4 */, float *kernel_ms, uint32_t repeats);
+
+/* ---- device-side unit entry points used by the parity tests (tests/ only) ------------------------------ */
+/* Evaluate n independent work items of test `kind` on the GPU; in/out are plain float arrays with
+ * in_stride/out_stride floats per item (layouts documented in tests/test_device_units.py). */
+int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out,
+                  uint32_t out_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMK_H */

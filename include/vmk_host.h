@@ -1,0 +1,61 @@
+/*
+ * vmk_host.h — C-ABI of the C++ host that keeps Vision's scene front-end (JSON schema, plugin type names and
+ * per-type defaults) and encodes a scene into the flat tables of include/vmk.h instead of emitting DSL.
+ *
+ * Reference interfaces replaced (Vision `src/`, file:line):
+ *   vmk_host_load_scene      Importer::import_scene -> SceneDesc::from_json -> Scene::init / Scene::prepare /
+ *                            Pipeline::prepare_geometry (host half)      importers/json/importer.cpp:16-23,
+ *                                                                         base/import/scene_desc.cpp:37-62,
+ *                                                                         base/import/node_desc.cpp (defaults),
+ *                                                                         base/mgr/scene.cpp:16-35,79-91,165-187
+ *   vmk_host_register_image  ocarina Image::load (image_pool.cpp:23-28)   decoded pixels are handed in by the caller;
+ *                                                                         .hdr/.pfm are decoded natively
+ * Error convention: 0 ok, negative on error, message via vmk_host_last_error() (thread-local).
+ */
+#ifndef VMK_HOST_H
+#define VMK_HOST_H
+
+#include "vmk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vmk_host_scene vmk_host_scene;
+
+typedef struct vmk_host_options {
+    uint32_t width, height;     /* 0 = keep pipeline.param.frame_buffer.param.resolution */
+    int32_t max_depth;          /* <0 = keep integrator.param.max_depth */
+    int32_t min_depth;          /* <0 = keep */
+    uint32_t procedural_env;    /* 1: a missing environment image is replaced by the seeded procedural sky */
+    uint32_t drop_unsupported_lights; /* 1: skip light types outside the hot-path scope (point/spot/projector) instead of failing */
+    const char *lut_path;       /* albedo-table blob (vision_amd/data/luts.bin); NULL = default next to the library */
+} vmk_host_options;
+
+/* Register decoded pixels for an image file so the loader does not need a decoder for it.  `path` is matched
+ * against the absolute path the scene resolves (scene_dir / fn).  8-bit: channels interleaved, is_float = 0;
+ * float: is_float = 1.  Pixels are copied. */
+int vmk_host_register_image(const char *path, uint32_t width, uint32_t height, uint32_t channels, int is_float,
+                            const void *pixels);
+void vmk_host_clear_images(void);
+
+/* List the image files a scene references (absolute paths, '\n' separated) so a caller can decode + register
+ * them.  Returns the number of bytes written (excluding the terminator) or a negative status. */
+int vmk_host_list_images(const char *json_path, char *buf, uint32_t buf_bytes);
+
+int vmk_host_load_scene(const char *json_path, const vmk_host_options *opt, vmk_host_scene **out);
+void vmk_host_free_scene(vmk_host_scene *scene);
+
+const vmk_scene *vmk_host_scene_tables(const vmk_host_scene *scene);
+const vmk_render_params *vmk_host_render_params(const vmk_host_scene *scene);
+uint32_t vmk_host_output_spp(const vmk_host_scene *scene);    /* output.spp (node_desc.cpp:360-369) */
+const char *vmk_host_output_fn(const vmk_host_scene *scene);  /* output.fn */
+/* one line per plugin object the scene instantiated: "category/type name" (Vision's plugin namespace) */
+const char *vmk_host_describe(const vmk_host_scene *scene);
+
+const char *vmk_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1515 @@
+// oracle/oracle.cpp — TEST INFRASTRUCTURE: CPU restatement of Vision's megakernel path-tracing hot path.
+//
+// NOT part of the product.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build,
+// link or call this file.  It restates, function by function, the arithmetic of the reference
+// (Royalvice/Vision, paths relative to its `src/`), consuming the same flat scene tables (include/vmk.h) the
+// HIP backend consumes, in plain scalar C++ (float32, -ffp-contract=off).
+//
+// Pinning: the ocarina submodule (DSL/RHI/OptiX layer) is absent from the reference checkout, so everything
+// that crosses into it (omath.h) is "parity unpinned".  The lobe / microfacet / Fresnel code is pinned by
+// re-integrating the reference's own precomputed albedo tables (tests/golden/lut_*.json, extracted from
+// base/scattering/precomputed_table.h by tools/make_golden_luts.py) — see tests/test_oracle_luts.py.
+#include "omath.h"
+#include "../include/vmk.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+namespace orc {
+
+// =====================================================================================================
+// a1. Sampler — render_core/sampler/independent.cpp:24-42, math/util.h:13-33, base/sampler.h:60-73
+// =====================================================================================================
+inline uint32_t tea(uint32_t v0, uint32_t v1) { // util.h:13-24, N = 4
+    uint32_t s0 = 0;
+    for (int n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+struct Sampler {
+    uint32_t state{0};
+    void start(uint32_t px, uint32_t py, uint32_t sample_index, uint32_t dim) { // independent.cpp:24-28
+        state = tea(tea(px, py), tea(sample_index, dim));
+    }
+    float next_1d() { // util.h:27-33
+        state = 1664525u * state + 1013904223u;
+        return ((float) (state & 0x00ffffffu) * 1.f) * (1.f / 16777216.f);
+    }
+    float2 next_2d() { float x = next_1d(); float y = next_1d(); return {x, y}; } // sampler.h:60-64
+};
+
+// =====================================================================================================
+// warps / MIS — math/warp.h
+// =====================================================================================================
+inline float2 square_to_disk(float2 u) { // warp.h:26-31
+    float r = sqrtf(u.x);
+    float theta = _2Pi * u.y;
+    float s, c; sincos_(theta, &s, &c);
+    return {r * c, r * s};
+}
+inline float3 square_to_cosine_hemisphere(float2 u) { // warp.h:38-43
+    float2 d = square_to_disk(u);
+    float z = sqrtf(fmax_(0.f, 1.f - d.x * d.x - d.y * d.y));
+    return {d.x, d.y, z};
+}
+inline float cosine_hemisphere_PDF(float cos_theta) { return cos_theta * InvPi; } // warp.h:46-49
+inline float2 square_to_triangle(float2 u) { float su0 = sqrtf(u.x); return {1.f - su0, u.y * su0}; } // warp.h:65-69
+inline float sample_linear(float u, float a, float b) { // warp.h:122-128
+    float x = u * (a + b) / (a + sqrtf(lerp_(u, sqr(a), sqr(b))));
+    float ret = fmin_(x, OneMinusEpsilon);
+    return (u == 0.f && a == 0.f) ? 0.f : ret;
+}
+inline float sample_tent(float u, float r) { // warp.h:131-146
+    return u < 0.5f ? -r * sample_linear((0.5f - u) * 2.f, 1.f, 0.f) : r * sample_linear((u - 0.5f) * 2.f, 1.f, 0.f);
+}
+inline float MIS_weight(float f_pdf, float g_pdf) { // warp.h:149-155,186-199: balance heuristic, nf = ng = 1
+    return (1.f * f_pdf) / (1.f * f_pdf + 1.f * g_pdf);
+}
+inline float PDF_wi(float pdf_point, float3 normal, float3 wo_un) { // warp.h:89-94
+    float cos_t = abs_(dot(normal, normalize(wo_un)));
+    return pdf_point * length_squared(wo_un) / cos_t;
+}
+inline float remapping(float a, float low, float high) { return (a - low) / (high - low); } // warp.h:18-23
+
+// =====================================================================================================
+// textures & LUTs — ocarina `tex.sample(n, uv)` (App. B: normalised coords, bilinear, texel centres at
+// (i+0.5)/N, repeat wrap for images, clamp for LUTs); image decode image_pool.cpp:13-35
+// =====================================================================================================
+struct SceneView;
+static float g_srgb_lut[256];
+static void init_srgb_lut() {
+    static bool done = false;
+    if (done) return;
+    for (int i = 0; i < 256; ++i) {
+        double c = i / 255.0;
+        g_srgb_lut[i] = (float) (c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
+    done = true;
+}
+inline float4 fetch_texel(const vmk_scene *s, const vmk_texture &t, int x, int y) {
+    const uint8_t *base = s->tex_data + t.offset;
+    size_t i = (size_t) y * t.width + (size_t) x;
+    if (t.format == VMK_TEX_RGBA32F) {
+        const float *p = (const float *) base + i * 4;
+        return {p[0], p[1], p[2], p[3]};
+    }
+    const uint8_t *p = base + i * 4;
+    if (t.format == VMK_TEX_RGBA8_SRGB) return {g_srgb_lut[p[0]], g_srgb_lut[p[1]], g_srgb_lut[p[2]], (float) p[3] * (1.f / 255.f)};
+    return {(float) p[0] * (1.f / 255.f), (float) p[1] * (1.f / 255.f), (float) p[2] * (1.f / 255.f), (float) p[3] * (1.f / 255.f)};
+}
+inline int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+inline float4 lerp4(float t, float4 a, float4 b) {
+    return {a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), a.w + t * (b.w - a.w)};
+}
+inline float4 sample_image(const vmk_scene *s, uint32_t tex_id, float2 uv) {
+    const vmk_texture &t = s->textures[tex_id];
+    float x = uv.x * (float) t.width - 0.5f, y = uv.y * (float) t.height - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float tx = x - fx0, ty = y - fy0;
+    int x0 = wrap_repeat((int) fx0, (int) t.width), y0 = wrap_repeat((int) fy0, (int) t.height);
+    int x1 = wrap_repeat((int) fx0 + 1, (int) t.width), y1 = wrap_repeat((int) fy0 + 1, (int) t.height);
+    float4 c00 = fetch_texel(s, t, x0, y0), c10 = fetch_texel(s, t, x1, y0);
+    float4 c01 = fetch_texel(s, t, x0, y1), c11 = fetch_texel(s, t, x1, y1);
+    return lerp4(ty, lerp4(tx, c00, c10), lerp4(tx, c01, c11));
+}
+inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+// 2-D LUT, `nc` interleaved channels, clamp addressing
+inline void sample_lut2d(const float *lut, int nc, float u, float v, float *out) {
+    const int N = VMK_LUT_RES;
+    float x = u * (float) N - 0.5f, y = v * (float) N - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float tx = x - fx0, ty = y - fy0;
+    int x0 = clampi((int) fx0, 0, N - 1), x1 = clampi((int) fx0 + 1, 0, N - 1);
+    int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
+    for (int c = 0; c < nc; ++c) {
+        float c00 = lut[(y0 * N + x0) * nc + c], c10 = lut[(y0 * N + x1) * nc + c];
+        float c01 = lut[(y1 * N + x0) * nc + c], c11 = lut[(y1 * N + x1) * nc + c];
+        out[c] = lerp_(ty, lerp_(tx, c00, c10), lerp_(tx, c01, c11));
+    }
+}
+inline void sample_lut3d(const float *lut, int nc, float3 uvw, float *out) {
+    const int N = VMK_LUT_RES;
+    float x = uvw.x * (float) N - 0.5f, y = uvw.y * (float) N - 0.5f, z = uvw.z * (float) N - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
+    float tx = x - fx0, ty = y - fy0, tz = z - fz0;
+    int x0 = clampi((int) fx0, 0, N - 1), x1 = clampi((int) fx0 + 1, 0, N - 1);
+    int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
+    int z0 = clampi((int) fz0, 0, N - 1), z1 = clampi((int) fz0 + 1, 0, N - 1);
+    for (int c = 0; c < nc; ++c) {
+        auto at = [&](int xi, int yi, int zi) { return lut[((zi * N + yi) * N + xi) * nc + c]; };
+        float a = lerp_(ty, lerp_(tx, at(x0, y0, z0), at(x1, y0, z0)), lerp_(tx, at(x0, y1, z0), at(x1, y1, z0)));
+        float b = lerp_(ty, lerp_(tx, at(x0, y0, z1), at(x1, y0, z1)), lerp_(tx, at(x0, y1, z1), at(x1, y1, z1)));
+        out[c] = lerp_(tz, a, b);
+    }
+}
+
+// slot evaluation — shader_node.cpp:242-273 (swizzle), number.cpp:106-109, image.cpp:87-97
+inline float3 eval_slot3(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
+    if (sl.tex == VMK_INVALID) return {sl.v[0], sl.v[1], sl.v[2]};
+    float4 t = sample_image(s, sl.tex & 0xffffu, uv);
+    float c[4] = {t.x * sl.v[0], t.y * sl.v[0], t.z * sl.v[0], t.w * sl.v[0]};
+    uint32_t sw = sl.tex >> 16;
+    return {c[sw & 3u], c[(sw >> 2) & 3u], c[(sw >> 4) & 3u]};
+}
+inline float eval_slot1(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
+    if (sl.tex == VMK_INVALID) return sl.v[0];
+    return eval_slot3(s, sl, uv).x;
+}
+
+// =====================================================================================================
+// a4. ray / triangle / BVH — Geometry::trace_closest / trace_occlusion (geometry.cpp:168-185)
+// The reference delegates to OptiX; the restatement is a Moeller-Trumbore test with the hit-selection rule
+// "smallest t wins, ties resolved towards the smaller (inst, prim)", valid hits 0 < t < t_max.
+// =====================================================================================================
+struct Ray { float3 o; float3 d; float t_max; };
+struct Hit { uint32_t inst{VMK_INVALID}, prim{VMK_INVALID}; float2 bary{0, 0}; uint32_t tri{VMK_INVALID};
+             bool is_miss() const { return inst == VMK_INVALID; } };
+
+inline bool intersect_tri(const vmk_tri_pos &tp, float3 o, float3 d, float *t_out, float *u_out, float *v_out) {
+    float3 p0 = {tp.p0[0], tp.p0[1], tp.p0[2]}, p1 = {tp.p1[0], tp.p1[1], tp.p1[2]}, p2 = {tp.p2[0], tp.p2[1], tp.p2[2]};
+    float3 e1 = p1 - p0, e2 = p2 - p0;
+    float3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    if (det == 0.f) return false;
+    float inv = 1.f / det;
+    float3 tvec = o - p0;
+    float u = dot(tvec, pvec) * inv;
+    if (!(u >= 0.f && u <= 1.f)) return false;
+    float3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv;
+    if (!(v >= 0.f && u + v <= 1.f)) return false;
+    float t = dot(e2, qvec) * inv;
+    *t_out = t; *u_out = u; *v_out = v;
+    return true;
+}
+
+struct BVHNode { float bmin[3], bmax[3]; int left, right; int first, count; };
+struct Counters { std::atomic<uint64_t> closest{0}, shadow{0}, nodes{0}, tris{0}, paths{0}, hits{0}, tex{0}; };
+
+struct SceneView {
+    const vmk_scene *s{};
+    std::vector<BVHNode> nodes;
+    std::vector<uint32_t> order; // BVH leaf order -> global triangle index
+    Counters cnt;
+
+    void build() {
+        uint32_t n = s->n_tris;
+        order.resize(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        std::vector<float> cen(3 * (size_t) n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const vmk_tri_pos &t = s->tri_pos[i];
+            for (int a = 0; a < 3; ++a) cen[3 * (size_t) i + a] = (t.p0[a] + t.p1[a] + t.p2[a]) * (1.f / 3.f);
+        }
+        nodes.clear();
+        nodes.reserve(2 * (size_t) n + 1);
+        if (n) build_rec(0, n, cen);
+    }
+    int build_rec(uint32_t lo, uint32_t hi, const std::vector<float> &cen) {
+        int idx = (int) nodes.size();
+        nodes.push_back({});
+        float bmin[3] = {1e30f, 1e30f, 1e30f}, bmax[3] = {-1e30f, -1e30f, -1e30f};
+        float cmin[3] = {1e30f, 1e30f, 1e30f}, cmax[3] = {-1e30f, -1e30f, -1e30f};
+        for (uint32_t i = lo; i < hi; ++i) {
+            const vmk_tri_pos &t = s->tri_pos[order[i]];
+            for (int a = 0; a < 3; ++a) {
+                bmin[a] = std::min(bmin[a], std::min(t.p0[a], std::min(t.p1[a], t.p2[a])));
+                bmax[a] = std::max(bmax[a], std::max(t.p0[a], std::max(t.p1[a], t.p2[a])));
+                float c = cen[3 * (size_t) order[i] + a];
+                cmin[a] = std::min(cmin[a], c); cmax[a] = std::max(cmax[a], c);
+            }
+        }
+        for (int a = 0; a < 3; ++a) { nodes[idx].bmin[a] = bmin[a]; nodes[idx].bmax[a] = bmax[a]; }
+        if (hi - lo <= 4) { nodes[idx].left = nodes[idx].right = -1; nodes[idx].first = (int) lo; nodes[idx].count = (int) (hi - lo); return idx; }
+        int axis = 0;
+        if (cmax[1] - cmin[1] > cmax[axis] - cmin[axis]) axis = 1;
+        if (cmax[2] - cmin[2] > cmax[axis] - cmin[axis]) axis = 2;
+        uint32_t mid = (lo + hi) / 2;
+        std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](uint32_t a, uint32_t b) {
+            return cen[3 * (size_t) a + axis] < cen[3 * (size_t) b + axis];
+        });
+        int l = build_rec(lo, mid, cen);
+        int r = build_rec(mid, hi, cen);
+        nodes[idx].left = l; nodes[idx].right = r; nodes[idx].count = 0;
+        return idx;
+    }
+    // conservative slab test (double precision, padded): never rejects a box containing a valid float32 hit
+    static bool hit_box(const BVHNode &nd, const Ray &r, float t_far) {
+        double t0 = 0.0, t1 = (double) t_far;
+        const float o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+        for (int a = 0; a < 3; ++a) {
+            double pad = 1e-4 * (1.0 + std::fabs((double) nd.bmin[a]) + std::fabs((double) nd.bmax[a]));
+            double lo = (double) nd.bmin[a] - pad, hi = (double) nd.bmax[a] + pad;
+            if (d[a] == 0.f) { if ((double) o[a] < lo || (double) o[a] > hi) return false; continue; }
+            double inv = 1.0 / (double) d[a];
+            double ta = (lo - (double) o[a]) * inv, tb = (hi - (double) o[a]) * inv;
+            if (ta > tb) std::swap(ta, tb);
+            t0 = std::max(t0, ta); t1 = std::min(t1, tb);
+            if (t0 > t1 * 1.0000001 + 1e-9) return false;
+        }
+        return true;
+    }
+    Hit trace_closest(const Ray &r) {
+        cnt.closest.fetch_add(1, std::memory_order_relaxed);
+        Hit best; float best_t = r.t_max;
+        if (nodes.empty()) return best;
+        int stack[128]; int sp = 0; stack[sp++] = 0;
+        uint64_t nn = 0, nt = 0;
+        while (sp) {
+            const BVHNode &nd = nodes[stack[--sp]];
+            ++nn;
+            if (!hit_box(nd, r, best_t)) continue;
+            if (nd.left < 0) {
+                for (int i = 0; i < nd.count; ++i) {
+                    uint32_t gi = order[nd.first + i];
+                    const vmk_tri_pos &tp = s->tri_pos[gi];
+                    float t, u, v; ++nt;
+                    if (!intersect_tri(tp, r.o, r.d, &t, &u, &v)) continue;
+                    if (!(t > 0.f && t < r.t_max)) continue;
+                    bool better = t < best_t || (t == best_t && !best.is_miss() && (tp.inst < best.inst || (tp.inst == best.inst && tp.prim < best.prim)));
+                    if (best.is_miss() && t <= best_t) better = true;
+                    if (better) { best_t = t; best.inst = tp.inst; best.prim = tp.prim; best.bary = {u, v}; best.tri = gi; }
+                }
+            } else { stack[sp++] = nd.left; stack[sp++] = nd.right; }
+        }
+        cnt.nodes.fetch_add(nn, std::memory_order_relaxed); cnt.tris.fetch_add(nt, std::memory_order_relaxed);
+        return best;
+    }
+    bool trace_occlusion(const Ray &r) {
+        cnt.shadow.fetch_add(1, std::memory_order_relaxed);
+        if (nodes.empty()) return false;
+        int stack[128]; int sp = 0; stack[sp++] = 0;
+        uint64_t nn = 0, nt = 0; bool occ = false;
+        while (sp && !occ) {
+            const BVHNode &nd = nodes[stack[--sp]];
+            ++nn;
+            if (!hit_box(nd, r, r.t_max)) continue;
+            if (nd.left < 0) {
+                for (int i = 0; i < nd.count; ++i) {
+                    float t, u, v; ++nt;
+                    if (!intersect_tri(s->tri_pos[order[nd.first + i]], r.o, r.d, &t, &u, &v)) continue;
+                    if (t > 0.f && t < r.t_max) { occ = true; break; }
+                }
+            } else { stack[sp++] = nd.left; stack[sp++] = nd.right; }
+        }
+        cnt.nodes.fetch_add(nn, std::memory_order_relaxed); cnt.tris.fetch_add(nt, std::memory_order_relaxed);
+        return occ;
+    }
+};
+
+// =====================================================================================================
+// a5. Interaction — Geometry::compute_surface_interaction (geometry.cpp:79-166), interaction.h:87-117
+// =====================================================================================================
+struct Interaction {
+    float3 pos, wo, ng;
+    float2 uv;
+    Frame shading;
+    float prim_area{0.f};
+    uint32_t prim_id{VMK_INVALID}, mat_id{VMK_INVALID}, light_id{VMK_INVALID};
+    bool has_material() const { return mat_id != VMK_INVALID; }
+    bool has_emission() const { return light_id != VMK_INVALID; }
+};
+inline float3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+inline float2 ld2(const float *p) { return {p[0], p[1]}; }
+inline float3 triangle_lerp(float2 b, float3 a0, float3 a1, float3 a2) { // App. B: (1-u-v) p0 + u p1 + v p2
+    return a0 * (1.f - b.x - b.y) + a1 * b.x + a2 * b.y;
+}
+inline float2 triangle_lerp2(float2 b, float2 a0, float2 a1, float2 a2) {
+    float w = 1.f - b.x - b.y;
+    return {a0.x * w + a1.x * b.x + a2.x * b.y, a0.y * w + a1.y * b.x + a2.y * b.y};
+}
+inline Interaction compute_surface_interaction(const vmk_scene *s, uint32_t tri, uint32_t inst_id, uint32_t prim_id,
+                                               float2 bary, bool is_complete) {
+    Interaction it;
+    const vmk_instance &inst = s->instances[inst_id];
+    const vmk_tri_pos &tp = s->tri_pos[tri];
+    const vmk_tri_attr &ta = s->tri_attr[tri];
+    it.prim_id = prim_id; it.light_id = inst.light_id; it.mat_id = inst.mat_id;
+    float3 p0 = ld3(tp.p0), p1 = ld3(tp.p1), p2 = ld3(tp.p2);
+    it.pos = triangle_lerp(bary, p0, p1, p2);
+    float3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float3 ng_un = cross(dp02, dp12);
+    it.prim_area = 0.5f * length(ng_un);
+    float2 t0 = ld2(ta.uv0), t1 = ld2(ta.uv1), t2 = ld2(ta.uv2);
+    float2 duv02 = t0 - t2, duv12 = t1 - t2;
+    float det = duv02.x * duv12.y - duv02.y * duv12.x;
+    bool degenerate_uv = abs_(det) < 1e-8f;
+    Frame frame;
+    if (is_complete) {
+        float3 dp_du, dp_dv;
+        if (!degenerate_uv) {
+            float inv_det = 1.f / det;
+            dp_du = normalize((dp02 * duv12.y - dp12 * duv02.y) * inv_det);
+            dp_dv = normalize((dp02 * (-duv12.x) + dp12 * duv02.x) * inv_det);
+        } else {
+            dp_du = normalize(p1 - p0);
+            dp_dv = normalize(p2 - p0);
+        }
+        frame = {dp_du, dp_dv, normalize(ng_un)};
+        float3 normal = triangle_lerp(bary, ld3(ta.n0), ld3(ta.n1), ld3(ta.n2));
+        it.shading = frame;
+        if (!is_zero(normal)) { // geometry.cpp:130-133 + PartialDerivative::update (interaction.h:101-105)
+            float3 ns = normalize(mul3x3(inst.n2w, normal));
+            it.shading.z = ns;
+            it.shading.x = normalize(cross(ns, it.shading.y)) * length(it.shading.x);
+            it.shading.y = normalize(cross(ns, it.shading.x)) * length(it.shading.y);
+        }
+    } else {
+        frame = {dp02, dp12, normalize(ng_un)};
+        it.shading = frame;
+    }
+    it.uv = triangle_lerp2(bary, t0, t1, t2);
+    it.ng = frame.z;
+    return it;
+}
+// geometry.h:64-69
+inline Interaction compute_surface_interaction(const vmk_scene *s, const Hit &hit, Ray &ray) {
+    Interaction it = compute_surface_interaction(s, hit.tri, hit.inst, hit.prim, hit.bary, true);
+    it.wo = normalize(-ray.d);
+    ray.t_max = length(it.pos - ray.o) / length(ray.d);
+    return it;
+}
+
+// a6. spawn rays — interaction.h:279-309, interaction.cpp:114-134
+inline Ray spawn_ray(float3 pos, float3 normal, float3 dir) {
+    normal = normal * (dot(normal, dir) > 0.f ? 1.f : -1.f);
+    return {offset_ray_origin(pos, normal), dir, RayTMax};
+}
+inline Ray spawn_ray_to(float3 p_start, float3 n_start, float3 p_target) {
+    float3 dir = p_target - p_start;
+    n_start = n_start * (dot(n_start, dir) > 0.f ? 1.f : -1.f);
+    return {offset_ray_origin(p_start, n_start), dir, 1.f - ShadowEpsilon};
+}
+inline float3 robust_pos(float3 pos, float3 ng, float3 dir, float factor) { // interaction.h:321-324
+    float f = dot(ng, dir) > 0.f ? 1.f : -1.f;
+    return offset_ray_origin(pos, (ng * f) * factor);
+}
+
+// =====================================================================================================
+// a13. microfacet — base/scattering/microfacet.{h,cpp} (GGX, sample_visible = true)
+// =====================================================================================================
+inline float2 calculate_alpha(float alpha, float anisotropic) { // microfacet.h:43-58
+    float ax = anisotropic < 0.f ? alpha / (1.f + anisotropic) : alpha * (1.f - anisotropic);
+    float ay = anisotropic < 0.f ? alpha * (1.f + anisotropic) : alpha / (1.f - anisotropic);
+    if (abs_(anisotropic) <= 1e-4f) return {alpha, alpha};
+    return {ax, ay};
+}
+inline float bsdf_D(float3 wh, float ax, float ay) { // microfacet.cpp:12-23
+    float3 H = {wh.x / ax, wh.y / ay, wh.z / 1.f};
+    float alpha2 = ax * ay;
+    return InvPi / (alpha2 * sqr(length_squared(H)));
+}
+inline float bsdf_lambda(float3 w, float ax, float ay) { // microfacet.cpp:41-47
+    float sqr_alpha_tan_n = (sqr(ax * w.x) + sqr(ay * w.y)) / sqr(w.z);
+    float ret = 0.5f * (sqrtf(1.0f + sqr_alpha_tan_n) - 1.0f);
+    return w.z == 0.f ? 0.f : ret;
+}
+inline float bsdf_G1(float3 w, float ax, float ay) { return 1.f / (1.f + bsdf_lambda(w, ax, ay)); } // microfacet.h:97-101
+inline float bsdf_G(float3 wo, float3 wi, float ax, float ay) { // microfacet.h:108-114
+    return 1.f / (1.f + bsdf_lambda(wo, ax, ay) + bsdf_lambda(wi, ax, ay));
+}
+inline float3 sample_GGX_VNDF(float3 Ve, float2 u, float ax, float ay) { // microfacet.cpp:73-95
+    float3 Vh = normalize(make_float3(ax * Ve.x, ay * Ve.y, Ve.z));
+    float lenSq = Vh.x * Vh.x + Vh.y * Vh.y;
+    float3 T1 = lenSq > 1e-7f ? make_float3(-Vh.y, Vh.x, 0.0f) / sqrtf(lenSq) : make_float3(1, 0, 0);
+    float3 T2 = lenSq > 1e-7f ? cross(Vh, T1) : make_float3(0.0f, 1.0f, 0.0f);
+    float2 t = square_to_disk(u);
+    t.y = lerp_(0.5f * (1.0f + Vh.z), safe_sqrt(1.0f - sqr(t.x)), t.y);
+    float3 Nh = T1 * t.x + T2 * t.y + Vh * safe_sqrt(1.0f - (t.x * t.x + t.y * t.y));
+    return normalize(make_float3(ax * Nh.x, ay * Nh.y, fmax_(0.0f, Nh.z)));
+}
+inline float3 sample_wh(float3 wo, float2 u, float ax, float ay) { // microfacet.cpp:102-112
+    bool flip = wo.z < 0.f;
+    float3 wh = sample_GGX_VNDF(flip ? -wo : wo, u, ax, ay);
+    return flip ? -wh : wh;
+}
+inline float PDF_wh(float3 wo, float3 wh, float ax, float ay) { // microfacet.cpp:152-159
+    return bsdf_D(wh, ax, ay) * bsdf_G1(wo, ax, ay) * abs_dot(wo, wh) / abs_cos_theta(wo);
+}
+inline float PDF_wi_reflection(float3 wo, float3 wh, float ax, float ay) { // microfacet.h:134-146
+    return PDF_wh(wo, wh, ax, ay) / (4.f * abs_dot(wo, wh));
+}
+inline float PDF_wi_transmission(float3 wo, float3 wh, float3 wi, float eta, float ax, float ay) { // microfacet.h:159-165
+    float denom = sqr(dot(wi, wh) * eta + dot(wo, wh));
+    float dwh_dwi = abs_dot(wi, wh) / denom;
+    return PDF_wh(wo, wh, ax, ay) * dwh_dwi;
+}
+inline float BRDF_div_fr(float3 wo, float3 wh, float3 wi, float ax, float ay) { // microfacet.h:168-175
+    return bsdf_D(wh, ax, ay) * bsdf_G(wo, wi, ax, ay) / abs_(4.f * cos_theta(wo) * cos_theta(wi));
+}
+inline float BTDF_div_ft(float3 wo, float3 wh, float3 wi, float eta, float ax, float ay, bool radiance) { // microfacet.cpp:166-179
+    float cos_i = cos_theta(wi), cos_o = cos_theta(wo);
+    float numerator = bsdf_D(wh, ax, ay) * bsdf_G(wo, wi, ax, ay) * abs_(dot(wi, wh) * dot(wo, wh));
+    float denom = sqr(dot(wi, wh) * eta + dot(wo, wh)) * abs_(cos_i * cos_o);
+    float ft = numerator / denom;
+    float factor = radiance ? rcp(sqr(eta)) : 1.f;
+    ft = denom == 0.f ? 0.f : ft;
+    return ft * factor;
+}
+
+// =====================================================================================================
+// a14. Fresnel — math/optics.h, math/complex.h, base/scattering/fresnel.h, metal.cpp:14-26
+// =====================================================================================================
+inline bool refract(float3 wi, float3 n, float eta, float3 *wt) { // optics.h:28-39
+    float cos_i = dot(n, wi);
+    float sin_i_2 = fmax_(0.f, 1.f - sqr(cos_i));
+    float sin_t_2 = sin_i_2 / sqr(eta);
+    bool valid = sin_t_2 < 1.f;
+    float cos_t = safe_sqrt(1.f - sin_t_2);
+    *wt = -wi / eta + n * (cos_i / eta - cos_t);
+    return valid;
+}
+inline float schlick_weight(float cos_t) { return pow5(clamp_(1.f - cos_t, 0.f, 1.f)); } // optics.h:42-45
+inline float schlick_F0_from_ior(float ior) { return sqr((ior - 1.0f) / (ior + 1.0f)); } // optics.h:60-62
+inline float schlick_ior_from_F0(float f0) { float s = sqrtf(clamp_(f0, 0.0f, 0.99f)); return (1.0f + s) / (1.0f - s); } // optics.h:65-68
+inline float fresnel_dielectric(float abs_cos_i, float eta) { // optics.h:71-78
+    float sin_i_2 = 1.f - sqr(abs_cos_i);
+    float sin_t_2 = sin_i_2 / sqr(eta);
+    float cos_t = safe_sqrt(1.f - sin_t_2);
+    float r_parl = (eta * abs_cos_i - cos_t) / (eta * abs_cos_i + cos_t);
+    float r_perp = (abs_cos_i - eta * cos_t) / (abs_cos_i + eta * cos_t);
+    return sin_t_2 >= 1.f ? 1.f : (sqr(r_parl) + sqr(r_perp)) * 0.5f;
+}
+struct Cpx { float re, im; };
+inline Cpx cadd(Cpx a, Cpx b) { return {a.re + b.re, a.im + b.im}; }
+inline Cpx csub(Cpx a, Cpx b) { return {a.re - b.re, a.im - b.im}; }
+inline Cpx cmul(Cpx a, Cpx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+inline Cpx cdiv(Cpx a, Cpx z) { float sc = 1.f / (z.re * z.re + z.im * z.im); return {sc * (a.re * z.re + a.im * z.im), sc * (a.im * z.re - a.re * z.im)}; }
+inline float cnorm_sqr(Cpx z) { return z.re * z.re + z.im * z.im; }
+inline Cpx csqrt(Cpx z) { // complex.h:61-69
+    float n = sqrtf(cnorm_sqr(z));
+    float t1 = sqrtf(0.5f * (n + abs_(z.re)));
+    float t2 = 0.5f * z.im / t1;
+    Cpx r;
+    r.re = n == 0.f ? 0.f : (z.re >= 0.f ? t1 : abs_(t2));
+    r.im = n == 0.f ? 0.f : (z.re >= 0.f ? t2 : u2f((f2u(t1) & 0x7fffffffu) | (f2u(z.im) & 0x80000000u)));
+    return r;
+}
+inline float fresnel_complex(float cos_i, float eta_re, float k) { // optics.h:93-102
+    Cpx eta = {eta_re, k};
+    float sin_i_2 = 1.f - sqr(cos_i);
+    Cpx sin_t_2 = cdiv(Cpx{sin_i_2, 0.f}, cmul(eta, eta));
+    Cpx cos_t = csqrt(csub(Cpx{1.f, 0.f}, sin_t_2));
+    Cpx ci = {cos_i, 0.f};
+    Cpx r_parl = cdiv(csub(cmul(eta, ci), cos_t), cadd(cmul(eta, ci), cos_t));
+    Cpx r_perp = cdiv(csub(ci, cmul(eta, cos_t)), cadd(ci, cmul(eta, cos_t)));
+    return (cnorm_sqr(r_parl) + cnorm_sqr(r_perp)) * .5f;
+}
+enum FresnelKind { FR_CONSTANT, FR_CONDUCTOR, FR_DIELECTRIC, FR_SCHLICK, FR_F82 };
+struct Fresnel {
+    int kind{FR_CONSTANT};
+    float3 a{1, 1, 1}; // conductor eta | schlick F0 | F82 F0
+    float3 b{0, 0, 0}; // conductor k   | F82 B
+    float eta{1.f};    // dielectric / schlick eta[0]
+    float3 evaluate(float cos_t) const {
+        switch (kind) {
+            case FR_CONDUCTOR: return {fresnel_complex(cos_t, a.x, b.x), fresnel_complex(cos_t, a.y, b.y), fresnel_complex(cos_t, a.z, b.z)};
+            case FR_DIELECTRIC: { float f = fresnel_dielectric(cos_t, eta); return {f, f, f}; }
+            case FR_SCHLICK: { // fresnel.h:60-67
+                float F_real = fresnel_dielectric(cos_t, eta);
+                float F0_real = schlick_F0_from_ior(eta);
+                float t = clamp_(inverse_lerp(F_real, F0_real, 1.f), 0.f, 1.f);
+                return lerp3(t, a, make_float3(1.f));
+            }
+            case FR_F82: { // fresnel.h:123-129
+                float mu = saturate_(1.f - cos_t);
+                float mu5 = pow5(mu);
+                float3 f_schlick = lerp3(mu5, a, make_float3(1.f));
+                return saturate3(f_schlick - b * cos_t * mu5 * mu);
+            }
+            default: return {1.f, 1.f, 1.f};
+        }
+    }
+};
+inline void f82_init(Fresnel &fr, float3 F82) { // fresnel.h:115-121
+    const float f = 6.f / 7.f;
+    const float f5 = pow5(f);
+    float3 one = make_float3(1.f);
+    float3 f_schlick = lerp3(f5, fr.a, one);
+    fr.b = f_schlick * (7.f / (f5 * f)) * (one - F82);
+}
+
+// =====================================================================================================
+// a11-a18. lobes — base/scattering/{bxdf,lobe}.{h,cpp}, render_core/material/*.cpp
+// =====================================================================================================
+namespace flag {
+constexpr uint32_t Unset = 1, Reflection = 2, Transmission = 4, Diffuse = 8, Glossy = 16, Specular = 32, NearSpec = 64;
+constexpr uint32_t DiffRefl = Diffuse | Reflection, GlossyRefl = Glossy | Reflection, GlossyTrans = Glossy | Transmission;
+}
+struct ScatterEval { float3 f{0, 0, 0}; float pdf{0.f}; uint32_t flags{flag::Unset}; bool valid() const { return pdf > 0.f; } };
+struct BSDFSample { ScatterEval eval; float3 wi{0, 0, 0}; float eta{1.f}; bool valid() const { return eval.valid(); } };
+struct SampledDirection { float3 wi{0, 0, 0}; bool valid{true}; };
+
+enum LobeKind { LB_LAMBERT, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_DIELECTRIC, LB_SHEEN };
+struct Lobe {
+    int kind{LB_LAMBERT};
+    Frame frame;
+    float3 kr{1, 1, 1};     // Lambert Kr / OrenNayar R / MicrofacetReflection kr / dielectric kt / sheen tint / blend Rd
+    float3 rs{0, 0, 0};     // FresnelBlend Rs
+    float A{0}, B{0};       // Oren-Nayar | sheen a,b
+    float ax{0}, ay{0};
+    Fresnel fr;
+    bool compensate{false}; // PureReflectionLobe::compensate (mirror / conductor / metallic)
+    uint32_t bxdf_flags{flag::DiffRefl};
+    float weight{1.f}, sample_weight{1.f};
+};
+struct LobeSet { int n{0}; bool is_set{false}; Lobe lobes[12]; };
+struct MatCtx { const vmk_scene *s; };
+
+inline float pure_reflection_compensate(const vmk_scene *s, const Lobe &l, float3 wo) { // lobe.cpp:716-720
+    float alpha = sqrtf(l.ax * l.ay); // MicrofacetBxDF::alpha_average (bxdf.h:116-118)
+    float v; sample_lut2d(s->luts.pure_reflection, 1, alpha, cos_theta(wo), &v);
+    return 1.f / v;
+}
+inline float dielectric_to_ratio_x(const Lobe &l) { return sqrtf(sqrtf(l.ax * l.ay)); } // lobe.h:250-255
+inline float2 dielectric_sample_lut(const vmk_scene *s, const Lobe &l, float3 wo, float eta) { // lobe.cpp:263-285
+    const float *lut = eta > 1.f ? s->luts.dielectric : s->luts.dielectric_inv;
+    float x = dielectric_to_ratio_x(l);
+    float y = abs_cos_theta(wo);
+    float z = eta > 1.f ? inverse_lerp(eta, 1.003f, 5.f) : inverse_lerp(rcp(eta), 1.003f, 5.f);
+    float out[2]; sample_lut3d(lut, 2, make_float3(x, y, z), out);
+    return {out[0], out[1]};
+}
+inline float dielectric_refl_prob(const Lobe &l, float3 F) { // lobe.cpp:315-319
+    float3 T = 1.f - F;
+    float3 total = T * l.kr + F;
+    return average(F) / average(total);
+}
+
+// FresnelBlend::f_specular (substrate.cpp:31-37): D(wh) / (4 |wi.wh| max(|cos_i|,|cos_o|)) * fresnel_schlick(Rs, wi.wh)
+inline float3 blend_f_specular(const Lobe &l, float3 wo, float3 wi, float3 wh) {
+    float3 specular = lerp3(schlick_weight(dot(wi, wh)), l.rs, make_float3(1.f)) *
+                      (bsdf_D(wh, l.ax, l.ay) / (4.f * abs_dot(wi, wh) * fmax_(abs_cos_theta(wi), abs_cos_theta(wo))));
+    return specular * (is_zero(wh) ? 0.f : 1.f);
+}
+
+// ---- local evaluate (Lobe::evaluate_local_impl of each lobe class) ----
+inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, float3 wi, bool radiance, float *eta_out) {
+    ScatterEval se;
+    switch (l.kind) {
+        case LB_LAMBERT: case LB_OREN_NAYAR: { // DiffuseLobe -> BxDF::safe_evaluate (bxdf.cpp:34-46)
+            bool sh = same_hemisphere(wo, wi);
+            float3 f;
+            if (l.kind == LB_LAMBERT) f = l.kr * InvPi; // bxdf.h:92-95
+            else { // OrenNayar::f bxdf.cpp:103-121
+                float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+                float d_cos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+                float max_cos = fmax_(0.f, d_cos);
+                bool cond = abs_cos_theta(wi) > abs_cos_theta(wo);
+                float sin_alpha = cond ? sin_o : sin_i;
+                float tan_beta = cond ? sin_i / abs_cos_theta(wi) : sin_o / abs_cos_theta(wo);
+                f = l.kr * InvPi * (l.A + l.B * max_cos * sin_alpha * tan_beta);
+            }
+            se.f = sh ? f : make_float3(0.f);
+            se.pdf = sh ? cosine_hemisphere_PDF(abs_cos_theta(wi)) : 0.f;
+            se.flags = flag::DiffRefl;
+            return se;
+        }
+        case LB_MICROFACET: { // MicrofacetLobe::evaluate_local_impl (lobe.cpp:213-218) + MicrofacetReflection (bxdf.cpp:65-78)
+            bool sh = same_hemisphere(wo, wi);
+            float3 wh = normalize(wo + wi);
+            float3 whf = face_forward(wh, make_float3(0, 0, 1));
+            float3 F = l.fr.evaluate(abs_dot(wo, whf));
+            float3 f = (F * BRDF_div_fr(wo, whf, wi, l.ax, l.ay)) * l.kr;
+            float pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay);
+            se.f = sh ? f : make_float3(0.f);
+            se.pdf = sh ? pdf : 0.f;
+            se.flags = flag::GlossyRefl;
+            if (l.compensate) se.f *= pure_reflection_compensate(s, l, wo); // lobe.cpp:722-729
+            return se;
+        }
+        case LB_FRESNEL_BLEND: { // substrate.cpp:12-70 through BxDF::safe_evaluate
+            bool sh = same_hemisphere(wo, wi);
+            float3 wh = normalize(wi + wo);
+            float3 specular = blend_f_specular(l, wo, wi, wh);
+            float3 diffuse = (28.f / (23.f * Pi)) * l.kr * (make_float3(1.f) - l.rs) *
+                             (1.f - pow5(1.f - .5f * abs_cos_theta(wi))) * (1.f - pow5(1.f - .5f * abs_cos_theta(wo)));
+            float3 f = specular + diffuse;
+            float fr = l.fr.evaluate(abs_cos_theta(wo)).x;
+            float pdf = lerp_(fr, cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
+            se.f = sh ? f : make_float3(0.f);
+            se.pdf = sh ? pdf : 0.f;
+            se.flags = flag::Reflection;
+            return se;
+        }
+        case LB_DIELECTRIC: { // lobe.cpp:321-412
+            bool refl = same_hemisphere(wo, wi);
+            float eta = l.fr.eta;
+            float eta_p = refl ? 1.f : eta;
+            if (eta_out) *eta_out = eta_p;
+            float3 wh = normalize(wo + wi * eta_p);
+            wh = face_forward(wh, wo);
+            float3 F = l.fr.evaluate(abs_dot(wh, wo));
+            float2 lut = dielectric_sample_lut(s, l, wo, eta);
+            if (refl) { // evaluate_reflection lobe.cpp:340-353
+                se.f = F * BRDF_div_fr(wo, wh, wi, l.ax, l.ay);
+                se.pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay) * dielectric_refl_prob(l, F);
+                se.flags = flag::GlossyRefl;
+                se.f *= rcp(lut.x);
+            } else { // evaluate_transmission lobe.cpp:355-371
+                float3 new_wh = face_forward(wh, wo);
+                float3 wh2 = normalize(wo + wi * eta); // GGXMicrofacet::BTDF(wo, wi, Ft, eta, tm) recomputes wh
+                float3 tr = (1.f - F) * BTDF_div_ft(wo, wh2, wi, eta, l.ax, l.ay, radiance);
+                se.f = tr * l.kr;
+                se.pdf = PDF_wi_transmission(wo, new_wh, wi, eta, l.ax, l.ay) * (1.f - dielectric_refl_prob(l, F));
+                se.flags = flag::GlossyTrans;
+                se.f *= rcp(lut.x);
+            }
+            return se;
+        }
+        case LB_SHEEN: { // principled_bsdf.cpp:58-72,110-117
+            float cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+            float3 w = make_float3(l.A * wi.x + l.B * wi.z, l.A * wi.y, wi.z); // inv_M
+            float len = length(w);
+            w = w / len;
+            float jacobian = sqr(l.A) / (len * len * len);
+            float ltc = cosine_hemisphere_PDF(cos_theta(w)) * jacobian;
+            se.f = l.kr * ltc / cos_i;
+            se.pdf = ltc;
+            if (cos_i < 0.f || cos_o < 0.f) se.f = make_float3(0.f);
+            se.flags = flag::Unset; // ScatterEval default: SheenLTC never assigns flags
+            return se;
+        }
+    }
+    return se;
+}
+
+// ---- local direction sampling (sample_wi_local_impl of each lobe class) ----
+inline SampledDirection sample_wi_local(const Lobe &l, float3 wo, Sampler &sampler) {
+    SampledDirection sd;
+    switch (l.kind) {
+        case LB_LAMBERT: case LB_OREN_NAYAR: { // BxDF::sample_wi bxdf.cpp:48-52
+            float3 wi = square_to_cosine_hemisphere(sampler.next_2d());
+            wi.z = wo.z < 0.f ? -wi.z : wi.z;
+            sd.wi = wi; sd.valid = true;
+            return sd;
+        }
+        case LB_MICROFACET: { // MicrofacetReflection::sample_wi bxdf.cpp:80-84
+            float3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
+            sd.wi = reflect(wo, wh);
+            sd.valid = same_hemisphere(wo, sd.wi);
+            return sd;
+        }
+        case LB_FRESNEL_BLEND: { // FresnelBlend::sample_wi substrate.cpp:52-69
+            float2 u = sampler.next_2d();
+            float fr = l.fr.evaluate(abs_cos_theta(wo)).x;
+            if (u.x < fr) {
+                u.x = remapping(u.x, 0.f, fr);
+                float3 wh = sample_wh(wo, u, l.ax, l.ay);
+                sd.wi = reflect(wo, wh);
+            } else {
+                u.x = remapping(u.x, fr, 1.f);
+                sd.wi = square_to_cosine_hemisphere(u);
+                sd.wi.z = wo.z < 0.f ? -sd.wi.z : sd.wi.z;
+            }
+            sd.valid = true;
+            return sd;
+        }
+        case LB_DIELECTRIC: { // lobe.cpp:431-449
+            float3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
+            float d = dot(wo, wh);
+            float3 F = l.fr.evaluate(abs_(d));
+            float uc = sampler.next_1d();
+            if (uc < dielectric_refl_prob(l, F)) {
+                sd.wi = reflect(wo, wh);
+                sd.valid = same_hemisphere(wo, sd.wi);
+            } else {
+                bool valid = refract(wo, wh, l.fr.eta, &sd.wi);
+                sd.valid = valid && !same_hemisphere(wo, sd.wi);
+            }
+            return sd;
+        }
+        case LB_SHEEN: { // principled_bsdf.cpp:100-108
+            float3 wi = square_to_cosine_hemisphere(sampler.next_2d());
+            wi = make_float3(wi.x / l.A - wi.z * l.B / l.A, wi.y / l.A, wi.z); // M
+            sd.wi = normalize(wi);
+            return sd;
+        }
+    }
+    return sd;
+}
+
+// Lobe::evaluate_impl (lobe.cpp:53-63,65-75): world -> local with the lobe's shading frame, f *= |cos_i|
+inline ScatterEval lobe_evaluate(const vmk_scene *s, const Lobe &l, float3 world_wo, float3 world_wi, bool radiance, float *eta) {
+    float3 wo = l.frame.to_local(world_wo), wi = l.frame.to_local(world_wi);
+    ScatterEval se = eval_local(s, l, wo, wi, radiance, eta);
+    se.f *= abs_cos_theta(wi);
+    return se;
+}
+inline float valid_world_factor(const Lobe &l, float3 wo, float3 wi) { // lobe.cpp:35-38, 373-375
+    if (l.kind == LB_DIELECTRIC) return 1.f;
+    return same_hemisphere(wo, wi, l.frame.z) ? 1.f : 0.f;
+}
+// LobeSet::evaluate_impl (lobe.cpp:673-688) or a single lobe
+inline ScatterEval set_evaluate(const vmk_scene *s, const LobeSet &ls, float3 world_wo, float3 world_wi, bool radiance, float *eta) {
+    if (!ls.is_set) return lobe_evaluate(s, ls.lobes[0], world_wo, world_wi, radiance, eta);
+    ScatterEval ret;
+    for (int i = 0; i < ls.n; ++i) {
+        const Lobe &l = ls.lobes[i];
+        ScatterEval se = lobe_evaluate(s, l, world_wo, world_wi, radiance, eta);
+        float factor = valid_world_factor(l, world_wo, world_wi);
+        se.f *= l.weight * factor;
+        se.pdf *= l.sample_weight * factor;
+        ret.f += se.f;
+        ret.pdf += se.pdf;
+        ret.flags |= se.flags;
+    }
+    return ret;
+}
+// Lobe::sample (lobe.cpp:111-119) with LobeSet::sample_wi_impl (lobe.cpp:629-658)
+inline BSDFSample set_sample(const vmk_scene *s, const LobeSet &ls, float3 world_wo, Sampler &sampler, bool radiance) {
+    BSDFSample ret;
+    SampledDirection sd;
+    if (ls.is_set) {
+        float uc = sampler.next_1d();
+        (void) sampler.next_2d();
+        int strategy = 0;
+        float sum_weights = 0.f;
+        for (int i = 0; i < ls.n; ++i) {
+            strategy = uc > sum_weights ? i : strategy;
+            sum_weights += ls.lobes[i].sample_weight;
+        }
+        const Lobe &l = ls.lobes[ls.n == 1 ? 0 : strategy];
+        sd = sample_wi_local(l, l.frame.to_local(world_wo), sampler);
+        sd.wi = l.frame.to_world(sd.wi);
+    } else {
+        const Lobe &l = ls.lobes[0];
+        sd = sample_wi_local(l, l.frame.to_local(world_wo), sampler);
+        sd.wi = l.frame.to_world(sd.wi);
+    }
+    ret.wi = sd.wi;
+    ret.eval = set_evaluate(s, ls, world_wo, sd.wi, radiance, &ret.eta);
+    ret.eval.pdf *= sd.valid ? 1.f : 0.f;
+    return ret;
+}
+
+// MaterialEvaluator::evaluate / sample with individual_ns (material.cpp:132-184)
+inline ScatterEval evaluator_evaluate(const vmk_scene *s, const LobeSet &ls, float3 ng, float3 wo, float3 wi) {
+    ScatterEval ret = set_evaluate(s, ls, wo, wi, true, nullptr);
+    bool discard = same_hemisphere(wo, wi, ng) == ((ret.flags & flag::Transmission) != 0);
+    if (discard) ret.pdf = 0.f;
+    return ret;
+}
+inline BSDFSample evaluator_sample(const vmk_scene *s, const LobeSet &ls, float3 ng, float3 wo, Sampler &sampler) {
+    BSDFSample ret = set_sample(s, ls, wo, sampler, true);
+    bool discard = same_hemisphere(wo, ret.wi, ng) == ((ret.eval.flags & flag::Transmission) != 0);
+    if (discard) ret.eval.pdf = 0.f;
+    return ret;
+}
+
+// ---- material -> lobes (create_lobe_set of each material plugin) ----
+inline float layering_weight_max(float3 layer_albedo, float3 weight) { // principled_bsdf.cpp:209-214
+    float3 tmp = {weight.x == 0.f ? 0.f : layer_albedo.x / weight.x, weight.y == 0.f ? 0.f : layer_albedo.y / weight.y,
+                  weight.z == 0.f ? 0.f : layer_albedo.z / weight.z};
+    return max_comp(tmp);
+}
+inline float3 layering_weight(float3 layer_albedo, float3 weight) {
+    return weight * saturate_(1.f - layering_weight_max(layer_albedo, weight));
+}
+inline void microfacet_alpha(const vmk_scene *s, const vmk_material &m, int slot_r, int slot_a, float2 uv, float rmin,
+                             float *ax, float *ay) { // metal.cpp:140-144, mirror.cpp:63-67, glass.cpp:245-249
+    float roughness = clamp_(eval_slot1(s, m.slot[slot_r], uv), rmin, 1.f);
+    float anisotropic = clamp_(eval_slot1(s, m.slot[slot_a], uv), -0.9f, 0.9f);
+    roughness = (m.flags & VMK_MATF_REMAP_ROUGHNESS) ? sqr(roughness) : roughness;
+    float2 a = calculate_alpha(roughness, anisotropic);
+    *ax = a.x; *ay = a.y;
+}
+inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const Interaction &it, Lobe &l) {
+    l = Lobe{};
+    l.frame = it.shading; // Material::compute_shading_frame without normal map (material.cpp:331-353)
+    switch (m.type) {
+        case VMK_MAT_DIFFUSE: { // diffuse.cpp:21-30
+            l.kr = eval_slot3(s, m.slot[0], it.uv);
+            if (m.flags & VMK_MATF_HAS_SIGMA) { // OrenNayar ctor bxdf.cpp:94-101
+                float sigma = eval_slot1(s, m.slot[1], it.uv);
+                sigma = sigma * PiOver2;
+                float sigma2 = sqr(sigma * sigma);
+                l.A = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                l.B = 0.45f * sigma2 / (sigma2 + 0.09f);
+                l.kind = LB_OREN_NAYAR;
+            } else l.kind = LB_LAMBERT;
+            l.bxdf_flags = flag::DiffRefl;
+            break;
+        }
+        case VMK_MAT_MIRROR: { // mirror.cpp:60-74
+            l.kind = LB_MICROFACET; l.kr = eval_slot3(s, m.slot[0], it.uv);
+            microfacet_alpha(s, m, 1, 2, it.uv, 0.0001f, &l.ax, &l.ay);
+            l.fr.kind = FR_CONSTANT; l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
+            break;
+        }
+        case VMK_MAT_METAL: { // metal.cpp:137-156
+            l.kind = LB_MICROFACET; l.kr = make_float3(1.f);
+            microfacet_alpha(s, m, 2, 3, it.uv, 0.0001f, &l.ax, &l.ay);
+            l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot3(s, m.slot[0], it.uv); l.fr.b = eval_slot3(s, m.slot[1], it.uv);
+            l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
+            break;
+        }
+        case VMK_MAT_GLASS: { // glass.cpp:240-257
+            l.kind = LB_DIELECTRIC; l.kr = eval_slot3(s, m.slot[0], it.uv);
+            float ior = eval_slot1(s, m.slot[1], it.uv);
+            float cos_t = dot(it.wo, it.ng); // Interaction::correct_eta interaction.cpp:80-83
+            ior = cos_t > 0.f ? ior : rcp(ior);
+            microfacet_alpha(s, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay);
+            l.fr.kind = FR_DIELECTRIC; l.fr.eta = ior;
+            break;
+        }
+        case VMK_MAT_SUBSTRATE: { // substrate.cpp:126-149
+            l.kind = LB_FRESNEL_BLEND;
+            l.kr = eval_slot3(s, m.slot[0], it.uv); l.rs = eval_slot3(s, m.slot[1], it.uv);
+            float ax, ay; microfacet_alpha(s, m, 2, 3, it.uv, 0.0001f, &ax, &ay);
+            if (m.flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
+            l.ax = clamp_(ax, 0.0001f, 1.f); l.ay = clamp_(ay, 0.0001f, 1.f);
+            l.fr.kind = FR_DIELECTRIC; l.fr.eta = 1.5f; l.bxdf_flags = flag::Reflection;
+            break;
+        }
+        default: break;
+    }
+}
+inline void build_principled(const vmk_scene *s, const vmk_material &m, const Interaction &it, LobeSet &out) { // principled_bsdf.cpp:352-461
+    out.is_set = true; out.n = 0;
+    float2 uv = it.uv;
+    float3 color = eval_slot3(s, m.slot[VMK_P_COLOR], uv);
+    float ior = eval_slot1(s, m.slot[VMK_P_IOR], uv);
+    float roughness = clamp_(eval_slot1(s, m.slot[VMK_P_ROUGHNESS], uv), 0.0001f, 1.f);
+    float anisotropic = eval_slot1(s, m.slot[VMK_P_ANISOTROPIC], uv);
+    float3 specular_tint = eval_slot3(s, m.slot[VMK_P_SPEC_TINT], uv);
+    float aspect = sqrtf(1.f - anisotropic * 0.9f);
+    float ax = fmax_(0.001f, sqr(roughness) / aspect), ay = fmax_(0.001f, sqr(roughness) * aspect);
+    float3 weight = make_float3(1.f);
+    float cos_t = dot(it.wo, it.ng);
+    float front_factor = cos_t > 0.f ? 1.f : 0.f;
+    auto push = [&](const Lobe &l) { out.lobes[out.n++] = l; };
+    if (s->luts.sheen_approx) { // sheen (Approximate mode default, principled_bsdf.cpp:260)
+        float3 sheen_tint = eval_slot3(s, m.slot[VMK_P_SHEEN_TINT], uv);
+        float sheen_weight = eval_slot1(s, m.slot[VMK_P_SHEEN_WEIGHT], uv) * front_factor;
+        float sheen_roughness = eval_slot1(s, m.slot[VMK_P_SHEEN_ROUGHNESS], uv);
+        Lobe l; l.kind = LB_SHEEN; l.frame = it.shading;
+        float c[4]; sample_lut2d(s->luts.sheen_approx, 4, cos_t, sheen_roughness, c);
+        l.A = c[0]; l.B = c[1];
+        l.kr = (sheen_tint * sheen_weight * weight) * c[2];
+        l.bxdf_flags = flag::GlossyRefl;
+        l.sample_weight = average(l.kr); l.weight = 1.f;
+        float3 albedo = l.kr;
+        push(l);
+        weight = layering_weight(albedo, weight);
+    }
+    { // coat
+        float cc_weight = eval_slot1(s, m.slot[VMK_P_COAT_WEIGHT], uv) * front_factor;
+        float cc_roughness = clamp_(eval_slot1(s, m.slot[VMK_P_COAT_ROUGHNESS], uv), 0.0001f, 1.f);
+        cc_roughness = sqr(cc_roughness);
+        float cc_ior = eval_slot1(s, m.slot[VMK_P_COAT_IOR], uv);
+        float3 cc_tint = eval_slot3(s, m.slot[VMK_P_COAT_TINT], uv);
+        Lobe l; l.kind = LB_MICROFACET; l.frame = it.shading; l.ax = l.ay = cc_roughness;
+        l.fr.kind = FR_DIELECTRIC; l.fr.eta = cc_ior;
+        l.kr = (weight * cc_weight) * cc_tint;
+        l.bxdf_flags = flag::GlossyRefl;
+        float x = sqrtf(sqrtf(l.ax * l.ay)); // MicrofacetLobe::to_ratio_x lobe.cpp:187-192
+        float z = inverse_lerp(cc_ior, 1.003f, 4.f);
+        float sv; sample_lut3d(s->luts.coat, 1, make_float3(x, cos_t, z), &sv);
+        float3 albedo = l.kr * sv;
+        l.sample_weight = average(albedo); l.weight = 1.f;
+        weight = layering_weight(albedo, weight);
+        push(l);
+    }
+    { // metallic
+        float metallic = eval_slot1(s, m.slot[VMK_P_METALLIC], uv) * front_factor;
+        Lobe l; l.kind = LB_MICROFACET; l.frame = it.shading; l.ax = ax; l.ay = ay;
+        l.fr.kind = FR_F82; l.fr.a = color; f82_init(l.fr, specular_tint);
+        l.kr = weight * metallic; l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
+        l.sample_weight = metallic * average(weight); l.weight = 1.f;
+        push(l);
+        weight *= (1.0f - metallic);
+    }
+    { // transmission
+        float trans_weight = eval_slot1(s, m.slot[VMK_P_TRANS_WEIGHT], uv);
+        float eta = cos_t > 0.f ? ior : rcp(ior);
+        float3 t_weight = weight * trans_weight;
+        Lobe l; l.kind = LB_DIELECTRIC; l.frame = it.shading; l.ax = ax; l.ay = ay;
+        l.fr.kind = FR_SCHLICK; l.fr.a = specular_tint * schlick_F0_from_ior(eta); l.fr.eta = eta;
+        l.kr = color;
+        l.sample_weight = average(t_weight); l.weight = average(t_weight);
+        push(l);
+        weight *= (1.0f - trans_weight);
+    }
+    { // specular
+        float f0 = schlick_F0_from_ior(ior);
+        Lobe l; l.kind = LB_MICROFACET; l.frame = it.shading; l.ax = ax; l.ay = ay;
+        l.fr.kind = FR_SCHLICK; l.fr.a = specular_tint * f0; l.fr.eta = ior;
+        l.kr = weight; l.bxdf_flags = flag::GlossyRefl;
+        float x = sqrtf(sqrtf(ax * ay));
+        float z = sqrtf(abs_((ior - 1.0f) / (ior + 1.0f))); // ior_to_ratio_z lobe.h:174-176
+        float sv; sample_lut3d(s->luts.specular, 1, make_float3(x, cos_t, z), &sv);
+        float3 albedo = lerp3(sv, l.fr.a, make_float3(1.f)) * l.kr;
+        l.sample_weight = average(albedo); l.weight = 1.f;
+        push(l);
+        weight = layering_weight(albedo, weight);
+    }
+    { // diffuse
+        float3 diff_weight = color * weight * front_factor;
+        Lobe l; l.kind = LB_LAMBERT; l.frame = it.shading; l.kr = diff_weight; l.bxdf_flags = flag::DiffRefl;
+        l.sample_weight = average(diff_weight); l.weight = 1.f;
+        push(l);
+    }
+    // LobeSet::initialize -> normalize_sampled_weight (lobe.cpp:524-532)
+    float weight_sum = 0.f;
+    for (int i = 0; i < out.n; ++i) weight_sum += out.lobes[i].sample_weight;
+    for (int i = 0; i < out.n; ++i) out.lobes[i].sample_weight = out.lobes[i].sample_weight / weight_sum;
+}
+inline void build_lobe_set(const vmk_scene *s, const vmk_material &m, const Interaction &it, LobeSet &out) {
+    if (m.type == VMK_MAT_PRINCIPLED) { build_principled(s, m, it, out); return; }
+    if (m.type == VMK_MAT_MIX) { // mix.cpp:66-71, LobeSet::create_mix + flatten (lobe.cpp:495-508,534-562)
+        float frac = eval_slot1(s, m.slot[0], it.uv);
+        float w[2] = {1.f - frac, frac};
+        out.is_set = true; out.n = 0;
+        for (int c = 0; c < 2; ++c) {
+            const vmk_material &cm = s->materials[c == 0 ? m.child0 : m.child1];
+            if (cm.type == VMK_MAT_PRINCIPLED) {
+                LobeSet sub; build_principled(s, cm, it, sub);
+                for (int i = 0; i < sub.n; ++i) { Lobe l = sub.lobes[i]; l.sample_weight *= w[c]; l.weight *= w[c]; out.lobes[out.n++] = l; }
+            } else {
+                Lobe l; build_simple_lobe(s, cm, it, l);
+                l.sample_weight = w[c]; l.weight = w[c];
+                out.lobes[out.n++] = l;
+            }
+        }
+        return;
+    }
+    out.is_set = false; out.n = 1;
+    build_simple_lobe(s, m, it, out.lobes[0]);
+}
+
+// =====================================================================================================
+// a7-a10. lights — base/illumination/lightsampler.cpp, render_core/light/area.cpp, environments/spherical.cpp,
+//                 render_core/warper/alias.h, alias2d.cpp
+// =====================================================================================================
+struct LightEval { float3 L{0, 0, 0}; float pdf{0.f}; };
+struct LightSample { LightEval eval; float3 p_light{0, 0, 0}; bool valid() const { return eval.pdf > 0.f; } };
+struct LightSampleContext { float3 pos, ng; };
+
+inline void alias_offset_u_remapped(const vmk_scene *s, uint32_t base, uint32_t size, float u, uint32_t *idx_out, float *u_remapped) { // alias.h:148-158
+    u = u * (float) size;
+    uint32_t idx = std::min((uint32_t) u, size - 1u);
+    u = fmin_(u - (float) idx, OneMinusEpsilon);
+    float prob = s->alias_prob[base + idx];
+    uint32_t alias = s->alias_idx[base + idx];
+    *u_remapped = u < prob ? fmin_(u / prob, OneMinusEpsilon) : fmin_((1.f - u) / (1.f - prob), OneMinusEpsilon);
+    *idx_out = u < prob ? idx : alias;
+}
+inline float alias_PMF(const vmk_scene *s, const vmk_light &l, uint32_t i) { // alias.h:50-52
+    return l.alias_integral > 0.f ? s->alias_func[l.alias_offset + i] / (l.alias_integral * (float) l.alias_count) : 0.f;
+}
+inline float alias_PDF(const vmk_scene *s, const vmk_light &l, uint32_t i) { // alias.h:44-46
+    return l.alias_integral > 0.f ? s->alias_func[l.alias_offset + i] / l.alias_integral : 0.f;
+}
+struct LightCtx { const vmk_scene *s; const vmk_render_params *p; };
+
+inline float light_select_PMF(const LightCtx &c, uint32_t index) { // lightsampler.cpp:159-176, uniform.cpp:13-20
+    uint32_t n = c.s->n_lights;
+    bool has_env = c.s->env_light != VMK_INVALID;
+    if (c.p->env_separate && has_env) {
+        float env_prob = c.p->env_prob;
+        uint32_t punctual = n - 1u;
+        if (index == c.s->env_light) return env_prob;
+        return (1.f - env_prob) * (1.f / (float) punctual);
+    }
+    return 1.f / (float) n;
+}
+inline void light_select(const LightCtx &c, float u, uint32_t *index, float *pmf) { // lightsampler.cpp:178-197, uniform.cpp:23-34
+    uint32_t n = c.s->n_lights;
+    bool has_env = c.s->env_light != VMK_INVALID;
+    if (c.p->env_separate && has_env) {
+        float env_prob = c.p->env_prob;
+        if (u < env_prob) { *index = c.s->env_light; *pmf = env_prob; return; }
+        u = remapping(u, env_prob, 1.f);
+        uint32_t punctual = n - 1u;
+        uint32_t idx = (uint32_t) fmin_(u * (float) punctual, (float) punctual - 1.f);
+        idx = idx < c.s->env_light ? idx : idx + 1u; // correct_index lightsampler.cpp:33-38
+        *index = idx; *pmf = (1.f / (float) punctual) * (1.f - env_prob);
+        return;
+    }
+    *index = (uint32_t) fmin_(u * (float) n, (float) n - 1.f);
+    *pmf = 1.f / (float) n;
+}
+inline float3 area_L(const vmk_scene *s, const vmk_light &l, float2 uv, float3 ng, float3 w) { // area.cpp:91-95
+    float3 radiance = eval_slot3(s, l.color, uv) * l.scale;
+    return radiance * ((dot(w, ng) > 0.f || l.two_sided) ? 1.f : 0.f);
+}
+inline float area_PDF_wi(float pdf_pos, float3 ng, float3 w) { // area.cpp:114-118
+    float ret = PDF_wi(pdf_pos, ng, w);
+    return (isinf_(ret) || isnan_(ret)) ? 0.f : ret;
+}
+inline LightSample area_sample_wi(const LightCtx &c, const vmk_light &l, const LightSampleContext &p_ref, float2 u) { // area.cpp:120-149
+    const vmk_scene *s = c.s;
+    uint32_t prim; float ur;
+    alias_offset_u_remapped(s, l.alias_offset, l.alias_count, u.x, &prim, &ur);
+    float pmf = alias_PMF(s, l, prim);
+    u.x = ur;
+    float2 bary = square_to_triangle(u);
+    uint32_t tri = s->instances[l.inst_id].tri_offset + prim;
+    Interaction it = compute_surface_interaction(s, tri, l.inst_id, prim, bary, false);
+    float pdf_pos = (1.f / it.prim_area) * pmf; // LightEvalContext(it) interaction.h:372-373
+    LightSample ret;
+    float3 w = p_ref.pos - it.pos;
+    ret.eval.L = area_L(s, l, it.uv, it.ng, w);
+    ret.eval.pdf = area_PDF_wi(pdf_pos, it.ng, w);
+    ret.p_light = robust_pos(it.pos, it.ng, w, c.p->ray_offset_factor);
+    return ret;
+}
+inline float3 env_L(const vmk_scene *s, const vmk_light &l, float3 local_dir) { // spherical.cpp:60-68
+    float2 uv = {spherical_phi(local_dir) * Inv2Pi, spherical_theta(local_dir) * InvPi};
+    return eval_slot3(s, l.color, uv) * l.scale;
+}
+inline float env_func_at(const vmk_scene *s, const vmk_light &l, uint32_t iu, uint32_t iv) { return s->alias_func[l.cond_offset + iv * l.res_x + iu]; }
+inline float env_map_PDF(const vmk_scene *s, const vmk_light &l, float2 p) { // alias2d.cpp:102-106
+    uint32_t iu = std::min((uint32_t) (p.x * (float) l.res_x), l.res_x - 1u);
+    uint32_t iv = std::min((uint32_t) (p.y * (float) l.res_y), l.res_y - 1u);
+    return l.alias_integral > 0.f ? env_func_at(s, l, iu, iv) / l.alias_integral : 0.f;
+}
+inline LightEval env_evaluate_wi(const vmk_scene *s, const vmk_light &l, float3 p_ref_pos, float3 p_light_pos) { // spherical.cpp:86-103
+    LightEval ret;
+    float3 world_dir = normalize(p_light_pos - p_ref_pos);
+    float3 local_dir = mul3x3(l.w2o, world_dir);
+    float theta = spherical_theta(local_dir), phi = spherical_phi(local_dir);
+    float sin_t = sin_(theta);
+    float2 uv = {phi * Inv2Pi, theta * InvPi};
+    ret.L = env_L(s, l, local_dir);
+    float pdf = env_map_PDF(s, l, uv) / (_2Pi * Pi * sin_t);
+    ret.pdf = sin_t == 0.f ? 0.f : pdf;
+    return ret;
+}
+inline LightSample env_sample_wi(const vmk_scene *s, const vmk_light &l, const LightSampleContext &p_ref, float2 u) { // spherical.cpp:105-125,162-168; alias2d.cpp:110-129
+    uint32_t iv; float urv;
+    alias_offset_u_remapped(s, l.alias_offset, l.alias_count, u.y, &iv, &urv);
+    float fv = ((float) iv + urv) / (float) l.alias_count;
+    float pdf_v = alias_PDF(s, l, iv);
+    uint32_t buffer_offset = l.res_x * iv;
+    uint32_t iu; float uru;
+    alias_offset_u_remapped(s, l.cond_offset + buffer_offset, l.res_x, u.x, &iu, &uru);
+    float fu = ((float) iu + uru) / (float) l.res_x;
+    float integral_u = s->alias_func[l.alias_offset + iv];
+    float func_u = s->alias_func[l.cond_offset + buffer_offset + iu];
+    float pdf_u = integral_u > 0.f ? func_u / integral_u : 0.f;
+    float pdf_map = pdf_u * pdf_v;
+    float2 uv = {fu, fv};
+    LightSample ret;
+    float theta = uv.y * Pi, phi = uv.x * _2Pi;
+    float sin_t, cos_t; sincos_(theta, &sin_t, &cos_t);
+    float3 local_dir = spherical_direction(sin_t, cos_t, phi);
+    float3 world_dir = normalize(mul3x3(l.o2w, local_dir));
+    float pdf_dir = pdf_map / (_2Pi * Pi * sin_t);
+    ret.eval.pdf = isinf_(pdf_dir) ? 0.f : pdf_dir;
+    ret.eval.L = env_L(s, l, local_dir);
+    ret.p_light = p_ref.pos + world_dir * l.world_diameter;
+    return ret;
+}
+inline LightSample light_sample_wi(const LightCtx &c, const LightSampleContext &lsc, Sampler &sampler) { // lightsampler.cpp:199-216
+    float u_light = sampler.next_1d();
+    float2 u_surface = sampler.next_2d();
+    uint32_t index; float pmf;
+    light_select(c, u_light, &index, &pmf);
+    const vmk_light &l = c.s->lights[index];
+    LightSample ls = l.type == VMK_LIGHT_AREA ? area_sample_wi(c, l, lsc, u_surface) : env_sample_wi(c.s, l, lsc, u_surface);
+    ls.eval.pdf *= pmf;
+    return ls;
+}
+inline LightEval light_evaluate_hit_wi(const LightCtx &c, const LightSampleContext &p_ref, const Interaction &it) { // lightsampler.cpp:252-267
+    LightEval ret;
+    const vmk_light &l = c.s->lights[it.light_id];
+    if (l.type != VMK_LIGHT_AREA) return ret;
+    float pdf_pos = (1.f / it.prim_area) * alias_PMF(c.s, l, it.prim_id);
+    float3 w = p_ref.pos - it.pos;
+    ret.L = area_L(c.s, l, it.uv, it.ng, w);
+    ret.pdf = area_PDF_wi(pdf_pos, it.ng, w);
+    ret.pdf *= light_select_PMF(c, it.light_id);
+    return ret;
+}
+inline LightEval light_evaluate_miss_wi(const LightCtx &c, const LightSampleContext &p_ref, float3 wi) { // lightsampler.cpp:290-300
+    const vmk_light &l = c.s->lights[c.s->env_light];
+    LightEval ret = env_evaluate_wi(c.s, l, p_ref.pos, p_ref.pos + wi);
+    ret.pdf *= light_select_PMF(c, c.s->env_light);
+    return ret;
+}
+
+// =====================================================================================================
+// a3. ray generation — sampler.h:65-73, box.cpp:16-20, triangle.cpp:16-18, fitted_curve.h:76-113,
+//     sensor.cpp:44-56, thin_lens.cpp:34-42
+// =====================================================================================================
+inline void table_offset(const float *prob, const uint32_t *alias, uint32_t size, float u, uint32_t *idx_out, float *u_remapped) {
+    u = u * (float) size;
+    uint32_t idx = std::min((uint32_t) u, size - 1u);
+    u = fmin_(u - (float) idx, OneMinusEpsilon);
+    float p = prob[idx];
+    *u_remapped = u < p ? fmin_(u / p, OneMinusEpsilon) : fmin_((1.f - u) / (1.f - p), OneMinusEpsilon);
+    *idx_out = u < p ? idx : alias[idx];
+}
+inline float2 filter_sample(const vmk_render_params &p, float2 u) {
+    if (p.filter_type == VMK_FILTER_BOX) return {lerp_(u.x, -p.filter_radius[0], p.filter_radius[0]), lerp_(u.y, -p.filter_radius[1], p.filter_radius[1])};
+    if (p.filter_type == VMK_FILTER_TRIANGLE) return {sample_tent(u.x, p.filter_radius[0]), sample_tent(u.y, p.filter_radius[1])};
+    // FilterSampler::sample (fitted_curve.h:76-83): alias-2D over |f| on the positive quadrant, mirrored by sign(u)
+    const uint32_t N = VMK_FILTER_TABLE_SIZE;
+    float2 v = {u.x * 2.f - 1.f, u.y * 2.f - 1.f};
+    float2 a = {abs_(v.x), abs_(v.y)};
+    uint32_t iv; float urv; table_offset(p.filter_marginal_prob, p.filter_marginal_alias, N, a.y, &iv, &urv);
+    float fv = ((float) iv + urv) / (float) N;
+    uint32_t iu; float uru; table_offset(p.filter_cond_prob + iv * N, p.filter_cond_alias + iv * N, N, a.x, &iu, &uru);
+    float fu = ((float) iu + uru) / (float) N;
+    float sx = v.x > 0.f ? 1.f : (v.x < 0.f ? -1.f : 0.f), sy = v.y > 0.f ? 1.f : (v.y < 0.f ? -1.f : 0.f);
+    return {fu * sx * p.filter_radius[0], fv * sy * p.filter_radius[1]};
+}
+inline Ray generate_ray(const vmk_render_params &p, uint32_t px, uint32_t py, Sampler &sampler) {
+    float2 fs = filter_sample(p, sampler.next_2d());
+    float2 p_film = {(float) px + 0.5f + fs.x, (float) py + 0.5f + fs.y};
+    float2 p_lens_u = sampler.next_2d();
+    (void) sampler.next_1d(); // time
+    float3 p_sensor = transform_point4(p.raster_to_sensor, make_float3(p_film.x, p_film.y, 0.f));
+    float3 dir = normalize(p_sensor);
+    float2 pl = square_to_disk(p_lens_u) * p.lens_radius;
+    float ft = p.focal_distance / dir.z;
+    float3 p_focus = dir * ft; // ray->at(ft) with origin 0
+    float3 org = make_float3(pl.x, pl.y, 0.f);
+    dir = normalize(p_focus - org);
+    Ray r;
+    r.o = transform_point4(p.c2w, org);
+    r.d = transform_vector4(p.c2w, dir);
+    r.t_max = RayTMax;
+    return r;
+}
+
+// =====================================================================================================
+// a20. IlluminationIntegrator::Li — base/integral/integrator.cpp:160-311 (no media), direct_lighting :20-37,
+//      evaluate_miss :137-158
+// =====================================================================================================
+struct PathStats { uint32_t closest{0}, shadow{0}, hits{0}; };
+
+inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sampler) {
+    const vmk_scene *s = sv.s;
+    LightCtx lc{s, &p};
+    float3 L = make_float3(0.f), T = make_float3(1.f);
+    float scatter_pdf = 1e16f;
+    float eta_scale = 1.f;
+    float3 prev_surface_ng = ray.d;
+    auto correct_bsdf_weight = [&](float weight, uint32_t bounce) { // integrator.h:146-159
+        if (p.mis_mode == 2) return 1.f;
+        if (p.mis_mode == 1) return bounce == 0 ? weight : 0.f;
+        return weight;
+    };
+    for (uint32_t bounces = 0; bounces < p.max_depth; ++bounces) {
+        Hit hit = sv.trace_closest(ray);
+        if (hit.is_miss()) { // evaluate_miss
+            if (s->env_light != VMK_INVALID) {
+                LightSampleContext p_ref{ray.o, prev_surface_ng};
+                LightEval eval = light_evaluate_miss_wi(lc, p_ref, ray.d);
+                float weight = correct_bsdf_weight(MIS_weight(scatter_pdf, eval.pdf), bounces);
+                L += (eval.L * 1.f * weight) * T;
+            }
+            break;
+        }
+        Interaction it = compute_surface_interaction(s, hit, ray);
+        if (!it.has_material()) { // integrator.cpp:208-214
+            ray = spawn_ray(it.pos, it.ng, ray.d);
+            bounces -= 1;
+            continue;
+        }
+        sv.cnt.hits.fetch_add(1, std::memory_order_relaxed);
+        if (it.has_emission()) { // integrator.cpp:221-231
+            LightSampleContext p_ref{ray.o, prev_surface_ng};
+            LightEval eval = light_evaluate_hit_wi(lc, p_ref, it);
+            float weight = correct_bsdf_weight(MIS_weight(scatter_pdf, eval.pdf), bounces);
+            L += eval.L * T * weight * 1.f;
+        }
+        prev_surface_ng = it.ng;
+        // NEE
+        LightSampleContext lsc{it.pos, it.ng};
+        LightSample ls = light_sample_wi(lc, lsc, sampler);
+        Ray shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
+        bool occluded = sv.trace_occlusion(shadow_ray);
+        LobeSet lobes;
+        build_lobe_set(s, s->materials[it.mat_id], it, lobes);
+        // direct_lighting (integrator.cpp:20-37) via direct_light_mis (integrator.h:164-176)
+        float3 wi = normalize(ls.p_light - it.pos);
+        ScatterEval scatter_eval = evaluator_evaluate(s, lobes, it.ng, it.wo, wi);
+        BSDFSample bs = evaluator_sample(s, lobes, it.ng, it.wo, sampler);
+        bool is_delta_light = ls.eval.pdf < 0.f;
+        bool mis = p.mis_mode != 1;
+        float weight = mis ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, scatter_eval.pdf)) : 1.f;
+        ls.eval.pdf = is_delta_light ? -ls.eval.pdf : ls.eval.pdf;
+        float3 Ld = make_float3(0.f);
+        if (!occluded && scatter_eval.valid() && ls.valid()) Ld = ls.eval.L * scatter_eval.f * weight / ls.eval.pdf;
+        if (p.mis_mode == 2) Ld = Ld * 0.f;
+        L += T * Ld * 1.f;
+        eta_scale *= sqr(bs.eta);
+        float lum = max_comp(T);
+        if (!bs.valid() || lum == 0.f) break;
+        T *= bs.eval.f / bs.eval.pdf;
+        if (eta_scale * lum < p.rr_threshold && bounces >= p.min_depth) { // integrator.cpp:292-299
+            float q = fmin_(0.95f, lum);
+            float rr = sampler.next_1d();
+            if (q < rr) break;
+            T = T / q;
+        }
+        scatter_pdf = bs.eval.pdf;
+        ray = spawn_ray(it.pos, it.ng, bs.wi);
+    }
+    return L;
+}
+
+inline uint32_t bitrev(uint32_t v, uint32_t bits) { uint32_t r = 0; for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | ((v >> i) & 1u); } return r; }
+inline bool tile_owned(const vmk_tiles *t, uint32_t px, uint32_t py, uint32_t width, uint32_t height) {
+    if (!t || t->tile_size == 0 || t->world <= 1) return true;
+    uint32_t tx = px / t->tile_size, ty = py / t->tile_size;
+    uint32_t ntx = (width + t->tile_size - 1) / t->tile_size;
+    uint32_t tile = ty * ntx + tx;
+    return (tile % t->world) == t->rank; // see DESIGN.md §e: interleaved ownership
+}
+
+}// namespace orc
+
+// =========================================================================================================
+// C entry points (ctypes)
+// =========================================================================================================
+using namespace orc;
+
+struct orc_scene_handle { SceneView sv; };
+
+extern "C" {
+
+void *orc_scene_create(const vmk_scene *scene) {
+    init_srgb_lut();
+    auto *h = new orc_scene_handle();
+    h->sv.s = scene;
+    h->sv.build();
+    return h;
+}
+void orc_scene_destroy(void *h) { delete (orc_scene_handle *) h; }
+
+// accum (width*height*4 floats) is updated in place: acc = lerp(1/(f+1), acc, L_f) (frame_buffer.cpp:117-126)
+int orc_render(void *h, const vmk_render_params *p, uint32_t frame_begin, uint32_t frame_count, const vmk_tiles *tiles,
+               float *accum, uint32_t n_threads, vmk_counters *counters) {
+    SceneView &sv = ((orc_scene_handle *) h)->sv;
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    std::atomic<uint32_t> next_row{0};
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t y = next_row.fetch_add(1);
+            if (y >= p->height) break;
+            for (uint32_t x = 0; x < p->width; ++x) {
+                if (!tile_owned(tiles, x, y, p->width, p->height)) continue;
+                float *px = accum + ((size_t) y * p->width + x) * 4;
+                float4 acc = {px[0], px[1], px[2], px[3]};
+                for (uint32_t f = frame_begin; f < frame_begin + frame_count; ++f) {
+                    Sampler sampler;
+                    sampler.start(x, y, f, 0); // rt_geom ray generation, frame_buffer.cpp:172-177
+                    Ray ray = generate_ray(*p, x, y, sampler);
+                    sampler.start(x, y, f, 1); // path_tracing kernel, integrator.cpp:93
+                    sv.cnt.paths.fetch_add(1, std::memory_order_relaxed);
+                    float3 L = Li(sv, *p, ray, sampler);
+                    float a = 1.f / (float) (f + 1u);
+                    float4 val = {L.x, L.y, L.z, 1.f};
+                    acc = lerp4(a, acc, val);
+                }
+                px[0] = acc.x; px[1] = acc.y; px[2] = acc.z; px[3] = acc.w;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    if (counters) {
+        counters->closest_rays = sv.cnt.closest; counters->shadow_rays = sv.cnt.shadow; counters->nodes_visited = sv.cnt.nodes;
+        counters->tris_tested = sv.cnt.tris; counters->paths = sv.cnt.paths; counters->surface_hits = sv.cnt.hits; counters->tex_fetches = sv.cnt.tex;
+    }
+    return 0;
+}
+
+void orc_reset_counters(void *h) {
+    Counters &c = ((orc_scene_handle *) h)->sv.cnt;
+    c.closest = 0; c.shadow = 0; c.nodes = 0; c.tris = 0; c.paths = 0; c.hits = 0; c.tex = 0;
+}
+
+int orc_trace_rays(void *h, uint32_t n, const float *org, const float *dir, const float *tmax, int any_hit, uint32_t *hit_out) {
+    SceneView &sv = ((orc_scene_handle *) h)->sv;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r{{org[3 * i], org[3 * i + 1], org[3 * i + 2]}, {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]}, tmax[i]};
+        if (any_hit) { hit_out[4 * i] = sv.trace_occlusion(r) ? 1u : 0u; hit_out[4 * i + 1] = hit_out[4 * i + 2] = hit_out[4 * i + 3] = 0; }
+        else {
+            Hit hh = sv.trace_closest(r);
+            hit_out[4 * i] = hh.inst; hit_out[4 * i + 1] = hh.prim; hit_out[4 * i + 2] = f2u(hh.bary.x); hit_out[4 * i + 3] = f2u(hh.bary.y);
+        }
+    }
+    return 0;
+}
+
+// exposure / tone map / gamma — frame_buffer.cpp:72-74,135-154, tonemapper/impl.cpp:16-45, pipeline.cpp:337-354
+static inline float tone1(uint32_t tm, float x) {
+    if (tm == 1) { float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f; return saturate_((x * (a * x + b)) / (x * (c * x + d) + e)); }
+    if (tm == 2) return x / (x + 1.f);
+    return x;
+}
+static inline float linear_to_srgb1(float x) { return x <= 0.0031308f ? 12.92f * x : 1.055f * (float) pow((double) x, 1.0 / 2.4) - 0.055f; }
+int orc_tonemap(const vmk_render_params *p, const float *accum, int final_picture, float *out) {
+    size_t n = (size_t) p->width * p->height;
+    for (size_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) {
+            float v = accum[4 * i + c];
+            v = 1.f - exp_(-v * p->exposure);
+            v = tone1(p->tone_mapper, v);
+            if (final_picture) { v = tone1(p->tone_mapper, v); v = linear_to_srgb1(v); }
+            out[4 * i + c] = v;
+        }
+        out[4 * i + 3] = 1.f;
+    }
+    return 0;
+}
+
+// ---- unit entry points mirrored by vmk_test_eval (tests/test_device_units.py documents the layouts) ----
+// kind 0: rng        in: px,py,frame,dim (as float-encoded uint bits)  out: 8 draws
+// kind 1: elementary in: x,y                                         out: sin x, cos x, acos clamp(x), atan2(y,x), exp(-|x|), sqrt|x|
+// kind 2: warps      in: u0,u1                                       out: disk(2) coshemi(3) tri(2) tent(1)
+// kind 3: microfacet in: wo(3) u(2) ax ay eta                        out: wh(3) D G1 pdf_wh Fd(eta) Fc(eta,k=3.5)
+// kind 4: bsdf       in: mat_id, px,py,frame, wo(3), wi(3), uvx, uvy  out: f(3) pdf flags | wi(3) f(3) pdf eta
+// kind 5: camera     in: px,py,frame                                 out: o(3) d(3)
+int orc_test_eval(void *h, const vmk_render_params *p, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
+    SceneView *sv = h ? &((orc_scene_handle *) h)->sv : nullptr;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *a = in + (size_t) i * in_stride;
+        float *o = out + (size_t) i * out_stride;
+        switch (kind) {
+            case 0: { Sampler s; s.start(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3])); for (int k = 0; k < 8; ++k) o[k] = s.next_1d(); break; }
+            case 1: {
+                float s, c; sincos_(a[0], &s, &c);
+                o[0] = s; o[1] = c; o[2] = acos_(clamp_(a[0], -1.f, 1.f)); o[3] = atan2_(a[1], a[0]); o[4] = exp_(-abs_(a[0])); o[5] = sqrtf(abs_(a[0]));
+                break;
+            }
+            case 2: {
+                float2 u = {a[0], a[1]};
+                float2 d = square_to_disk(u); float3 c = square_to_cosine_hemisphere(u); float2 t = square_to_triangle(u);
+                o[0] = d.x; o[1] = d.y; o[2] = c.x; o[3] = c.y; o[4] = c.z; o[5] = t.x; o[6] = t.y; o[7] = sample_tent(a[0], 0.5f);
+                break;
+            }
+            case 3: {
+                float3 wo = normalize(make_float3(a[0], a[1], a[2]));
+                float3 wh = sample_wh(wo, {a[3], a[4]}, a[5], a[6]);
+                o[0] = wh.x; o[1] = wh.y; o[2] = wh.z; o[3] = bsdf_D(wh, a[5], a[6]); o[4] = bsdf_G1(wo, a[5], a[6]);
+                o[5] = PDF_wh(wo, wh, a[5], a[6]); o[6] = fresnel_dielectric(abs_dot(wo, wh), a[7]); o[7] = fresnel_complex(abs_dot(wo, wh), a[7], 3.5f);
+                break;
+            }
+            case 4: {
+                const vmk_scene *s = sv->s;
+                uint32_t mat_id = f2u(a[0]);
+                Interaction it;
+                it.pos = make_float3(0, 0, 0); it.ng = make_float3(0, 0, 1);
+                it.shading = {make_float3(1, 0, 0), make_float3(0, 1, 0), make_float3(0, 0, 1)};
+                it.wo = normalize(make_float3(a[4], a[5], a[6]));
+                it.uv = {a[10], a[11]};
+                it.mat_id = mat_id;
+                float3 wi = normalize(make_float3(a[7], a[8], a[9]));
+                LobeSet ls; build_lobe_set(s, s->materials[mat_id], it, ls);
+                ScatterEval se = evaluator_evaluate(s, ls, it.ng, it.wo, wi);
+                Sampler smp; smp.start(f2u(a[1]), f2u(a[2]), f2u(a[3]), 1);
+                BSDFSample bs = evaluator_sample(s, ls, it.ng, it.wo, smp);
+                o[0] = se.f.x; o[1] = se.f.y; o[2] = se.f.z; o[3] = se.pdf; o[4] = u2f(se.flags);
+                o[5] = bs.wi.x; o[6] = bs.wi.y; o[7] = bs.wi.z; o[8] = bs.eval.f.x; o[9] = bs.eval.f.y; o[10] = bs.eval.f.z; o[11] = bs.eval.pdf; o[12] = bs.eta;
+                break;
+            }
+            case 5: {
+                Sampler s; s.start(f2u(a[0]), f2u(a[1]), f2u(a[2]), 0);
+                Ray r = generate_ray(*p, f2u(a[0]), f2u(a[1]), s);
+                o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+                break;
+            }
+            default: return -1;
+        }
+    }
+    return 0;
+}
+
+// ---- albedo-table re-integration (pins the lobe code against the reference's precomputed_table.h) ----
+// Material::precompute_lobe (material.h:121-163): texel (x,y,z) of a res^3 (or res^2) grid, ratio = idx/(res-1),
+// sampler.start((x,y), 0, 0), Lobe::precompute_with_radio + integral_albedo (lobe.cpp:13-33) in Importance mode.
+// which: 0 PureReflection (mirror.cpp:53-57, lobe.h:344-356), 1 Dielectric, 2 DielectricInv (glass.cpp:14-76),
+//        3 Specular (principled_bsdf.cpp:177-190), 4 Coat (principled_bsdf.cpp:135-146)
+int orc_integrate_albedo(uint32_t which, uint32_t res, uint32_t x, uint32_t y, uint32_t z, uint32_t sample_num, float *out2) {
+    Sampler sampler; sampler.start(x, y, 0, 0);
+    float rx = (float) x / (float) (res - 1), ry = (float) y / (float) (res - 1), rz = which == 0 ? 0.f : (float) z / (float) (res - 1);
+    Lobe l;
+    l.frame = {make_float3(1, 0, 0), make_float3(0, 1, 0), make_float3(0, 0, 1)};
+    float a = clamp_(sqr(rx), 0.001f, 1.f); // from_ratio_x lobe.cpp:183-185 / glass.cpp:36-40
+    l.ax = l.ay = a;
+    float cos_t = clamp_(ry, 1e-4f, 1.0f); // from_ratio_y lobe.cpp:158-164
+    float3 wo = make_float3(sqrtf(1.f - sqr(cos_t)), 0.f, cos_t);
+    switch (which) {
+        case 0: l.kind = LB_MICROFACET; l.fr.kind = FR_CONSTANT; l.kr = make_float3(1.f); break;
+        case 1: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 5.f); l.kr = make_float3(1.f); break;
+        case 2: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = rcp(lerp_(rz, 1.003f, 5.f)); l.kr = make_float3(1.f); break;
+        case 3: l.kind = LB_MICROFACET; l.fr.kind = FR_SCHLICK; l.fr.a = make_float3(0.04f); l.fr.eta = schlick_ior_from_F0(pow4(rz)); l.kr = make_float3(1.f); break;
+        case 4: l.kind = LB_MICROFACET; l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 4.f); l.kr = make_float3(1.f); break;
+        default: return -1;
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    static const float unit_lut[2] = {1.f, 1.f};
+    for (uint32_t i = 0; i < sample_num; ++i) {
+        SampledDirection sd = sample_wi_local(l, wo, sampler);
+        float eta_dummy;
+        ScatterEval se;
+        if (l.kind == LB_DIELECTRIC) { // DielectricPrecompute::compensate() == false (glass.cpp:17)
+            // evaluate without LUT compensation
+            bool refl = same_hemisphere(wo, sd.wi);
+            float eta = l.fr.eta, eta_p = refl ? 1.f : eta;
+            float3 wh = face_forward(normalize(wo + sd.wi * eta_p), wo);
+            float3 F = l.fr.evaluate(abs_dot(wh, wo));
+            if (refl) { se.f = F * BRDF_div_fr(wo, wh, sd.wi, l.ax, l.ay); se.pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay) * dielectric_refl_prob(l, F); }
+            else {
+                float3 wh2 = normalize(wo + sd.wi * eta);
+                se.f = ((1.f - F) * BTDF_div_ft(wo, wh2, sd.wi, eta, l.ax, l.ay, false)) * l.kr;
+                se.pdf = PDF_wi_transmission(wo, face_forward(wh, wo), sd.wi, eta, l.ax, l.ay) * (1.f - dielectric_refl_prob(l, F));
+            }
+        } else {
+            se = eval_local(nullptr, l, wo, sd.wi, false, &eta_dummy);
+        }
+        se.pdf *= sd.valid ? 1.f : 0.f;
+        if (se.pdf > 0.f) {
+            float r = (se.f.x / se.pdf) * abs_cos_theta(sd.wi);
+            acc0 += (double) r;
+            if (same_hemisphere(sd.wi, wo)) acc1 += (double) r;
+        }
+    }
+    (void) unit_lut;
+    out2[0] = (float) (acc0 / sample_num);
+    out2[1] = (float) (acc1 / sample_num);
+    return 0;
+}
+
+
+// whole table, threaded; nc = 2 floats per texel for the dielectric tables (total, reflected), else 1
+int orc_integrate_albedo_table(uint32_t which, uint32_t res, uint32_t sample_num, float *out, uint32_t n_threads) {
+    uint32_t depth = which == 0 ? 1u : res;
+    uint32_t nc = (which == 1 || which == 2) ? 2u : 1u;
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    std::atomic<uint32_t> next{0};
+    uint32_t total = res * res * depth;
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= total) break;
+            uint32_t x = i % res, y = (i / res) % res, z = i / (res * res);
+            float v[2];
+            orc_integrate_albedo(which, res, x, y, z, sample_num, v);
+            for (uint32_t c = 0; c < nc; ++c) out[(size_t) i * nc + c] = v[c];
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    return 0;
+}
+
+}// extern "C"

@@ -1,0 +1,118 @@
+"""TEST INFRASTRUCTURE — ctypes binding of the CPU oracle (oracle/oracle.cpp).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  The product package
+(vision_amd/) never does: its render path fails loudly when the HIP library is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_DIR)
+_SO = os.path.join(_DIR, "_build", "liboracle.so")
+_LIB = None
+
+
+def build(force=False):
+    src = [os.path.join(_DIR, "oracle.cpp"), os.path.join(_DIR, "omath.h"), os.path.join(_ROOT, "include", "vmk.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", _SO, src[0], "-lpthread"]
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.c_void_p]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                 C.c_void_p]
+        L.orc_reset_counters.argtypes = [C.c_void_p]
+        L.orc_trace_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_test_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                    C.c_void_p, C.c_uint32]
+        L.orc_integrate_albedo.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleScene:
+    """CPU oracle bound to host tables (a vision_amd.host.HostScene keeps them alive)."""
+
+    def __init__(self, host_scene):
+        self.host_scene = host_scene
+        self._h = lib().orc_scene_create(C.cast(host_scene.tables, C.c_void_p))
+
+    def render(self, params, frame_begin, frame_count, accum=None, tiles=None, threads=0):
+        from vision_amd import _abi
+        w, h = params.width, params.height
+        if accum is None:
+            accum = np.zeros((h, w, 4), dtype=np.float32)
+        cnt = _abi.Counters()
+        lib().orc_reset_counters(self._h)
+        lib().orc_render(self._h, C.byref(params), frame_begin, frame_count, C.byref(tiles) if tiles else None,
+                         _ptr(accum), threads, C.byref(cnt))
+        return accum, cnt.as_dict()
+
+    def trace(self, org, dirs, tmax, any_hit=False):
+        n = org.shape[0]
+        org = np.ascontiguousarray(org, np.float32)
+        dirs = np.ascontiguousarray(dirs, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        out = np.zeros((n, 4), np.uint32)
+        lib().orc_trace_rays(self._h, n, _ptr(org), _ptr(dirs), _ptr(tmax), int(any_hit), _ptr(out))
+        return out
+
+    def test_eval(self, params, kind, inp, out_stride):
+        inp = np.ascontiguousarray(inp, np.float32)
+        out = np.zeros((inp.shape[0], out_stride), np.float32)
+        rc = lib().orc_test_eval(self._h, C.byref(params) if params is not None else None, kind, inp.shape[0], _ptr(inp),
+                                 inp.shape[1], _ptr(out), out_stride)
+        assert rc == 0
+        return out
+
+    def close(self):
+        if self._h:
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def test_eval_noscene(kind, inp, out_stride, params=None):
+    inp = np.ascontiguousarray(inp, np.float32)
+    out = np.zeros((inp.shape[0], out_stride), np.float32)
+    rc = lib().orc_test_eval(None, C.byref(params) if params is not None else None, kind, inp.shape[0], _ptr(inp),
+                             inp.shape[1], _ptr(out), out_stride)
+    assert rc == 0
+    return out
+
+
+def tonemap(params, accum, final_picture=False):
+    out = np.zeros_like(accum)
+    lib().orc_tonemap(C.byref(params), _ptr(np.ascontiguousarray(accum, np.float32)), int(final_picture), _ptr(out))
+    return out
+
+
+def integrate_albedo(which, res, x, y, z, samples):
+    out = np.zeros(2, np.float32)
+    lib().orc_integrate_albedo(which, res, x, y, z, samples, _ptr(out))
+    return out

@@ -1,0 +1,886 @@
+// vmk_host.cpp — C++ host: Vision JSON scene -> flat vmk tables (include/vmk.h).
+//
+// Mirrors Vision's scene front-end (plugin category/type names, per-type defaults, JSON spelling) but, instead of
+// instantiating DSL-emitting plugin objects, each "plugin" here only ENCODES its parameters into SoA tables.
+// Reference call stack being re-expressed (Vision `src/`):
+//   JsonImporter::read_file -> SceneDesc::from_json             importers/json/importer.cpp:16-23, base/import/scene_desc.cpp:37-62
+//   Scene::init (light_sampler, spectrum, materials, sensor, shapes, integrator, sampler)   base/mgr/scene.cpp:16-35
+//   Scene::prepare (tidy_up, fill_instances, lights.prepare, materials.prepare)             base/mgr/scene.cpp:79-91,165-187
+//   Geometry::update_instances / upload                                                      base/mgr/geometry.cpp:20-34,64-71
+#include "../../../include/vmk_host.h"
+#include "json.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace vmk {
+
+static thread_local std::string g_error;
+struct HostError : std::runtime_error { using std::runtime_error::runtime_error; };
+[[noreturn]] static void fail(const std::string &m) { throw HostError(m); }
+
+// ------------------------------------------------------------------------------------------------
+// small double-precision matrix helpers (column-major 4x4, m[col*4+row] like ocarina float4x4)
+// ------------------------------------------------------------------------------------------------
+struct Mat4 {
+    double m[16];
+    static Mat4 identity() { Mat4 r{}; for (int i = 0; i < 4; ++i) r.m[i * 4 + i] = 1.0; return r; }
+    double &at(int row, int col) { return m[col * 4 + row]; }
+    double at(int row, int col) const { return m[col * 4 + row]; }
+};
+static Mat4 operator*(const Mat4 &a, const Mat4 &b) {
+    Mat4 r{};
+    for (int c = 0; c < 4; ++c) for (int rr = 0; rr < 4; ++rr) { double s = 0; for (int k = 0; k < 4; ++k) s += a.at(rr, k) * b.at(k, c); r.at(rr, c) = s; }
+    return r;
+}
+static Mat4 translation(double x, double y, double z) { Mat4 r = Mat4::identity(); r.at(0, 3) = x; r.at(1, 3) = y; r.at(2, 3) = z; return r; }
+static Mat4 scale(double x, double y, double z) { Mat4 r = Mat4::identity(); r.at(0, 0) = x; r.at(1, 1) = y; r.at(2, 2) = z; return r; }
+static double radians(double d) { return d * M_PI / 180.0; }
+static Mat4 rotation_x(double deg) { double c = std::cos(radians(deg)), s = std::sin(radians(deg)); Mat4 r = Mat4::identity(); r.at(1, 1) = c; r.at(1, 2) = -s; r.at(2, 1) = s; r.at(2, 2) = c; return r; }
+static Mat4 rotation_y(double deg) { double c = std::cos(radians(deg)), s = std::sin(radians(deg)); Mat4 r = Mat4::identity(); r.at(0, 0) = c; r.at(0, 2) = s; r.at(2, 0) = -s; r.at(2, 2) = c; return r; }
+static Mat4 rotation_z(double deg) { double c = std::cos(radians(deg)), s = std::sin(radians(deg)); Mat4 r = Mat4::identity(); r.at(0, 0) = c; r.at(0, 1) = -s; r.at(1, 0) = s; r.at(1, 1) = c; return r; }
+static Mat4 inverse(const Mat4 &a) {
+    double inv[16], det; const double *m = a.m;
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0) fail("singular transform matrix");
+    Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = inv[i] / det;
+    return r;
+}
+struct V3 { double x, y, z; };
+static V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static V3 normalize(V3 a) { double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return {a.x / l, a.y / l, a.z / l}; }
+// ocarina look_at<H>: returns the camera-to-world frame with columns (right, up, forward, position); consistent
+// with Sensor::update_mat / camera_to_world_rotation (sensor.cpp:73-78,153-162): right = fwd x up, up' = right x fwd.
+static Mat4 look_at(V3 pos, V3 target, V3 up) {
+    V3 fwd = normalize(target - pos);
+    V3 right = normalize(cross(fwd, up));
+    V3 up2 = cross(right, fwd);
+    Mat4 r = Mat4::identity();
+    r.at(0, 0) = right.x; r.at(1, 0) = right.y; r.at(2, 0) = right.z;
+    r.at(0, 1) = up2.x; r.at(1, 1) = up2.y; r.at(2, 1) = up2.z;
+    r.at(0, 2) = fwd.x; r.at(1, 2) = fwd.y; r.at(2, 2) = fwd.z;
+    r.at(0, 3) = pos.x; r.at(1, 3) = pos.y; r.at(2, 3) = pos.z;
+    return r;
+}
+static V3 json_v3(const Json &j, V3 d) { if (!j.is_array() || j.size() < 3) return d; return {j.at(0).as_double(0), j.at(1).as_double(0), j.at(2).as_double(0)}; }
+// TransformDesc::init (node_desc.cpp:31-58)
+static Mat4 parse_transform(const Json &ps) {
+    if (ps.is_null()) return Mat4::identity();
+    std::string type = ps["type"].as_string("matrix4x4");
+    const Json &param = ps["param"];
+    if (type == "look_at") return look_at(json_v3(param["position"], {0, 0, 0}), json_v3(param["target_pos"], {0, 0, 1}), json_v3(param["up"], {0, 1, 0}));
+    if (type == "Euler") {
+        V3 p = json_v3(param["position"], {0, 0, 0});
+        return translation(p.x, p.y, p.z) * rotation_x(param["pitch"].as_double(0)) * rotation_z(param["roll"].as_double(0)) * rotation_y(param["yaw"].as_double(0));
+    }
+    if (type == "trs") {
+        V3 t = json_v3(param["t"], {0, 0, 0}), s = json_v3(param["s"], {1, 1, 1});
+        const Json &r = param["r"]; // (axis xyz, angle degrees)
+        double ax = 1, ay = 0, az = 0, ang = 0;
+        if (r.is_array() && r.size() >= 4) { ax = r.at(0).as_double(1); ay = r.at(1).as_double(0); az = r.at(2).as_double(0); ang = r.at(3).as_double(0); }
+        V3 a = normalize({ax, ay, az}); double c = std::cos(radians(ang)), sn = std::sin(radians(ang));
+        Mat4 R = Mat4::identity();
+        R.at(0, 0) = c + a.x * a.x * (1 - c); R.at(0, 1) = a.x * a.y * (1 - c) - a.z * sn; R.at(0, 2) = a.x * a.z * (1 - c) + a.y * sn;
+        R.at(1, 0) = a.y * a.x * (1 - c) + a.z * sn; R.at(1, 1) = c + a.y * a.y * (1 - c); R.at(1, 2) = a.y * a.z * (1 - c) - a.x * sn;
+        R.at(2, 0) = a.z * a.x * (1 - c) - a.y * sn; R.at(2, 1) = a.z * a.y * (1 - c) + a.x * sn; R.at(2, 2) = c + a.z * a.z * (1 - c);
+        return translation(t.x, t.y, t.z) * R * scale(s.x, s.y, s.z);
+    }
+    if (type == "matrix4x4") {
+        const Json &mm = param["matrix4x4"];
+        Mat4 r = Mat4::identity();
+        if (mm.is_array() && mm.size() == 4) for (int c = 0; c < 4; ++c) for (int rr = 0; rr < 4; ++rr) r.at(rr, c) = mm.at(c).at(rr).as_double(rr == c ? 1.0 : 0.0);
+        return r;
+    }
+    fail("transform type error " + type);
+}
+
+// ------------------------------------------------------------------------------------------------
+// images
+// ------------------------------------------------------------------------------------------------
+struct Image { uint32_t w{0}, h{0}, channels{0}; bool is_float{false}; std::vector<uint8_t> u8; std::vector<float> f32; };
+static std::map<std::string, Image> g_images;
+
+static bool ends_with(const std::string &s, const std::string &suf) { return s.size() >= suf.size() && std::equal(suf.rbegin(), suf.rend(), s.rbegin(), [](char a, char b) { return std::tolower(a) == std::tolower(b); }); }
+static std::string dir_of(const std::string &p) { size_t i = p.find_last_of('/'); return i == std::string::npos ? "." : p.substr(0, i); }
+static std::string join_path(const std::string &dir, const std::string &fn) { if (!fn.empty() && fn[0] == '/') return fn; return dir + "/" + fn; }
+static bool file_exists(const std::string &p) { std::ifstream f(p, std::ios::binary); return (bool) f; }
+
+// Radiance .hdr (RGBE, new-style RLE) — native decoder
+static bool load_hdr(const std::string &path, Image &img) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string line; bool fmt = false;
+    std::getline(f, line);
+    if (line.rfind("#?", 0) != 0) return false;
+    while (std::getline(f, line) && !line.empty()) if (line.find("FORMAT=32-bit_rle_rgbe") != std::string::npos) fmt = true;
+    (void) fmt;
+    std::getline(f, line);
+    int w = 0, h = 0;
+    if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2) return false;
+    img.w = w; img.h = h; img.channels = 3; img.is_float = true; img.f32.assign((size_t) w * h * 4, 1.f);
+    std::vector<uint8_t> scan((size_t) w * 4);
+    for (int y = 0; y < h; ++y) {
+        uint8_t hd[4]; f.read((char *) hd, 4);
+        if (!f) return false;
+        if (hd[0] == 2 && hd[1] == 2 && ((hd[2] << 8) | hd[3]) == w && w >= 8 && w < 32768) {
+            for (int c = 0; c < 4; ++c) {
+                int x = 0;
+                while (x < w) {
+                    uint8_t n; f.read((char *) &n, 1);
+                    if (n > 128) { uint8_t v; f.read((char *) &v, 1); n -= 128; while (n-- && x < w) scan[(size_t) x++ * 4 + c] = v; }
+                    else { while (n-- && x < w) { uint8_t v; f.read((char *) &v, 1); scan[(size_t) x++ * 4 + c] = v; } }
+                }
+            }
+        } else {
+            std::memcpy(scan.data(), hd, 4);
+            f.read((char *) scan.data() + 4, (std::streamsize) ((size_t) w * 4 - 4));
+        }
+        for (int x = 0; x < w; ++x) {
+            const uint8_t *p = &scan[(size_t) x * 4];
+            float sc = p[3] ? std::ldexp(1.f, (int) p[3] - 136) : 0.f;
+            float *o = &img.f32[((size_t) y * w + x) * 4];
+            o[0] = p[0] * sc; o[1] = p[1] * sc; o[2] = p[2] * sc; o[3] = 1.f;
+        }
+    }
+    return true;
+}
+
+// Seeded procedural environment used when the scene's HDRI is stripped from the reference checkout
+// (classroom: spaichingen_hill_2k.exr).  Closed form, no RNG: clear-sky gradient + sun disc +
+// ground, lat-long 2048x1024, row 0 = zenith.  Documented in DESIGN.md §"stand-in assets".
+static void procedural_sky(Image &img) {
+    const uint32_t W = 2048, H = 1024;
+    img.w = W; img.h = H; img.channels = 3; img.is_float = true; img.f32.resize((size_t) W * H * 4);
+    const double sun_el = radians(32.0), sun_az = radians(250.0);
+    const double sx = std::cos(sun_el) * std::cos(sun_az), sy = std::cos(sun_el) * std::sin(sun_az), sz = std::sin(sun_el);
+    for (uint32_t y = 0; y < H; ++y) {
+        double theta = (y + 0.5) / H * M_PI;
+        double cz = std::cos(theta), sn = std::sin(theta);
+        for (uint32_t x = 0; x < W; ++x) {
+            double phi = (x + 0.5) / W * 2.0 * M_PI;
+            double dx = sn * std::cos(phi), dy = sn * std::sin(phi), dz = cz;
+            double r, g, b;
+            if (dz >= 0) {
+                double t = std::pow(1.0 - dz, 3.0);
+                r = 0.0022 * (1 - t) + 0.0085 * t; g = 0.0040 * (1 - t) + 0.0090 * t; b = 0.0085 * (1 - t) + 0.0095 * t;
+            } else { r = 0.0016; g = 0.0014; b = 0.0011; }
+            double cs = dx * sx + dy * sy + dz * sz;
+            double ang = std::acos(std::min(1.0, std::max(-1.0, cs)));
+            double sun = 6.0 * std::exp(-(ang * ang) / (2 * 0.02 * 0.02)) + 0.02 * std::exp(-(ang * ang) / (2 * 0.25 * 0.25));
+            r += sun * 1.0; g += sun * 0.93; b += sun * 0.80;
+            float *o = &img.f32[((size_t) y * W + x) * 4];
+            o[0] = (float) r; o[1] = (float) g; o[2] = (float) b; o[3] = 1.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene builder
+// ------------------------------------------------------------------------------------------------
+struct MetalIor { const char *name; float eta[3]; float k[3]; };
+static const MetalIor kMetals[] = {
+#include "metal_ior_rgb.inl"
+};
+
+struct AliasBuild { std::vector<float> prob; std::vector<uint32_t> alias; std::vector<float> func; float integral{0}; };
+// AliasTable::build (render_core/warper/alias.h:86-122)
+static AliasBuild build_alias(std::vector<float> weights) {
+    AliasBuild out;
+    size_t n = weights.size();
+    double sum = 0.0; for (float w : weights) sum += (double) w;
+    double ratio = (double) n / sum;
+    std::vector<uint32_t> over, under;
+    out.prob.resize(n); out.alias.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        float p = (float) ((double) weights[i] * ratio);
+        out.prob[i] = p; out.alias[i] = i;
+        (p > 1.0f ? over : under).push_back(i);
+    }
+    while (!over.empty() && !under.empty()) {
+        uint32_t o = over.back(), u = under.back();
+        over.pop_back(); under.pop_back();
+        out.prob[o] -= 1.0f - out.prob[u];
+        out.alias[u] = o;
+        if (out.prob[o] > 1.0f) over.push_back(o);
+        else if (out.prob[o] < 1.0f) under.push_back(o);
+    }
+    for (uint32_t i : over) { out.prob[i] = 1.0f; out.alias[i] = i; }
+    for (uint32_t i : under) { out.prob[i] = 1.0f; out.alias[i] = i; }
+    out.integral = (float) (sum / (double) n);
+    out.func = std::move(weights);
+    return out;
+}
+
+struct SlotSpec { int dim; std::vector<float> def; };
+
+struct HostScene {
+    std::string scene_dir;
+    vmk_host_options opt{};
+    // tables
+    std::vector<vmk_tri_pos> tri_pos;
+    std::vector<vmk_tri_attr> tri_attr;
+    std::vector<vmk_instance> instances;
+    std::vector<vmk_material> materials;
+    std::vector<std::string> material_names;
+    std::vector<vmk_light> lights;
+    std::vector<vmk_texture> textures;
+    std::vector<uint8_t> tex_data;
+    std::map<std::string, uint32_t> tex_index;
+    std::vector<float> alias_prob, alias_func;
+    std::vector<uint32_t> alias_idx;
+    std::vector<float> luts;
+    vmk_scene scene{};
+    vmk_render_params params{};
+    uint32_t output_spp{0};
+    std::string output_fn;
+    std::string description;
+    std::vector<std::string> image_paths;
+    bool list_only{false};
+    double bmin[3] = {1e300, 1e300, 1e300}, bmax[3] = {-1e300, -1e300, -1e300};
+
+    void describe(const std::string &cat, const std::string &type, const std::string &name) { description += cat + "/" + type + " " + name + "\n"; }
+
+    // ---- textures (ImagePool::load_texture image_pool.cpp:13-35) ----
+    uint32_t obtain_texture(const std::string &fn, std::string color_space, bool allow_procedural) {
+        std::string path = join_path(scene_dir, fn);
+        if (color_space.empty()) color_space = (ends_with(fn, ".exr") || ends_with(fn, ".hdr")) ? "linear" : "srgb";
+        std::string key = path + "|" + color_space;
+        auto it = tex_index.find(key);
+        if (it != tex_index.end()) return it->second;
+        image_paths.push_back(path);
+        if (list_only) { tex_index[key] = 0; return 0; }
+        Image local;
+        const Image *img = nullptr;
+        auto reg = g_images.find(path);
+        if (reg != g_images.end()) img = &reg->second;
+        else if (ends_with(fn, ".hdr") && load_hdr(path, local)) img = &local;
+        else if (allow_procedural && opt.procedural_env) { procedural_sky(local); img = &local; describe("image", "procedural_sky", fn + " (stand-in: file missing)"); }
+        else fail("image '" + path + "' is neither registered (vmk_host_register_image) nor decodable natively" + (file_exists(path) ? "" : " (file missing)"));
+        vmk_texture t{};
+        while (tex_data.size() % 16) tex_data.push_back(0);
+        t.offset = tex_data.size(); t.width = img->w; t.height = img->h; t.channels = img->channels;
+        size_t n = (size_t) img->w * img->h;
+        if (img->is_float) {
+            t.format = VMK_TEX_RGBA32F;
+            size_t off = tex_data.size(); tex_data.resize(off + n * 16);
+            float *dst = (float *) (tex_data.data() + off);
+            if (img->f32.size() == n * 4) std::memcpy(dst, img->f32.data(), n * 16);
+            else for (size_t i = 0; i < n; ++i) for (int c = 0; c < 4; ++c) dst[i * 4 + c] = c < (int) img->channels ? img->f32[i * img->channels + c] : (c == 3 ? 1.f : (img->channels == 1 ? img->f32[i] : 0.f));
+        } else {
+            t.format = color_space == "linear" ? VMK_TEX_RGBA8_LINEAR : VMK_TEX_RGBA8_SRGB;
+            size_t off = tex_data.size(); tex_data.resize(off + n * 4);
+            uint8_t *dst = tex_data.data() + off;
+            for (size_t i = 0; i < n; ++i) for (int c = 0; c < 4; ++c) dst[i * 4 + c] = c < (int) img->channels ? img->u8[i * img->channels + c] : (c == 3 ? 255 : (img->channels == 1 ? img->u8[i] : 0));
+        }
+        uint32_t id = (uint32_t) textures.size();
+        textures.push_back(t);
+        tex_index[key] = id;
+        return id;
+    }
+
+    // ---- slots: SlotDesc::init / ShaderNodeDesc::init (node_desc.cpp:128-151,307-335), swizzle shader_node.cpp:242-273 ----
+    static uint32_t channel_mask(const std::string &channels, int dim) {
+        uint32_t sw = 0;
+        for (int i = 0; i < 3; ++i) {
+            char ch = i < (int) channels.size() ? (char) std::tolower(channels[i]) : (dim == 1 ? channels[0] : "xyz"[i]);
+            uint32_t idx = (ch == 'x' || ch == 'r') ? 0 : (ch == 'y' || ch == 'g') ? 1 : (ch == 'z' || ch == 'b') ? 2 : 3;
+            sw |= idx << (2 * i);
+        }
+        return sw;
+    }
+    vmk_slot parse_slot(const Json &param, const std::string &key, int dim, std::vector<float> def, bool env_image = false) {
+        vmk_slot sl{}; sl.tex = VMK_INVALID;
+        const Json &ps = param[key];
+        std::string channels = dim == 1 ? "x" : "xyz";
+        const Json *node = &ps;
+        if (ps.is_object() && ps.contains("channels")) { channels = ps["channels"].as_string(channels); node = &ps["node"]; }
+        std::vector<float> value = def;
+        std::string fn, color_space; float tex_scale = 1.f; bool is_image = false;
+        if (node->is_null()) { /* default */ }
+        else if (node->is_array()) value = node->as_float_vector();
+        else if (node->is_number()) value = {node->as_float(0.f)};
+        else if (node->is_object()) {
+            const Json *p = node;
+            std::string type;
+            if (!node->contains("param")) type = (*node)["type"].as_string("image");
+            else { type = (*node)["type"].as_string(); p = &(*node)["param"]; }
+            if (type == "image") { is_image = true; fn = (*p)["fn"].as_string(); color_space = (*p)["color_space"].as_string(); tex_scale = (*p)["scale"].as_float(1.f); }
+            else if (type == "number" || type == "constant") { const Json &v = (*p)["value"]; if (!v.is_null()) value = v.as_float_vector(); }
+            else fail("shader node type '" + type + "' (slot '" + key + "') is outside the hot-path scope (number/constant/image only)");
+        }
+        if (is_image) {
+            uint32_t id = obtain_texture(fn, color_space, env_image);
+            sl.v[0] = tex_scale; sl.v[1] = sl.v[2] = 0.f;
+            sl.tex = (id & 0xffffu) | (channel_mask(channels, dim) << 16);
+            return sl;
+        }
+        if (value.empty()) value = def;
+        if ((int) channels.size() > 1 && value.size() == 1) value = std::vector<float>(channels.size(), value[0]); // scalar broadcast
+        float c[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < value.size() && i < 4; ++i) c[i] = value[i];
+        uint32_t sw = channel_mask(channels, dim);
+        sl.v[0] = c[sw & 3u]; sl.v[1] = dim == 1 ? 0.f : c[(sw >> 2) & 3u]; sl.v[2] = dim == 1 ? 0.f : c[(sw >> 4) & 3u];
+        return sl;
+    }
+
+    // ---- materials (Scene::load_materials scene.cpp:111-118; initialize_slots of each plugin) ----
+    uint32_t add_material(const Json &desc) {
+        std::string type = desc["type"].as_string("diffuse");
+        std::string name = desc["name"].as_string();
+        const Json &p = desc["param"];
+        vmk_material m{};
+        for (auto &s : m.slot) s.tex = VMK_INVALID;
+        m.child0 = m.child1 = VMK_INVALID;
+        if (p.contains("normal")) fail("material '" + name + "': normal maps are outside the hot-path scope");
+        bool remap = p["remapping_roughness"].as_bool(true);
+        if (remap) m.flags |= VMK_MATF_REMAP_ROUGHNESS;
+        if (type == "diffuse") { // diffuse.cpp:41-48
+            m.type = VMK_MAT_DIFFUSE;
+            m.slot[0] = parse_slot(p, "color", 3, {0.5f, 0.5f, 0.5f});
+            if (p.contains("sigma")) { m.flags |= VMK_MATF_HAS_SIGMA; m.slot[1] = parse_slot(p, "sigma", 1, {0.5f}); }
+        } else if (type == "mirror") { // mirror.cpp:35-41
+            m.type = VMK_MAT_MIRROR;
+            m.slot[0] = parse_slot(p, "color", 3, {1, 1, 1}); m.slot[1] = parse_slot(p, "roughness", 1, {0.001f}); m.slot[2] = parse_slot(p, "anisotropic", 1, {0.f});
+        } else if (type == "metal") { // metal.cpp:59-65,104-129 (srgb: SPD evaluated at the 3 peak wavelengths on the host)
+            m.type = VMK_MAT_METAL;
+            std::string mname = p["material_name"].as_string();
+            const MetalIor *mi = &kMetals[0]; // names[0] when not found (sorted map order in the reference: "Ag")
+            for (auto &k : kMetals) if (mname == k.name) mi = &k;
+            m.slot[0].v[0] = mi->eta[0]; m.slot[0].v[1] = mi->eta[1]; m.slot[0].v[2] = mi->eta[2];
+            m.slot[1].v[0] = mi->k[0]; m.slot[1].v[1] = mi->k[1]; m.slot[1].v[2] = mi->k[2];
+            m.slot[2] = parse_slot(p, "roughness", 1, {0.01f}); m.slot[3] = parse_slot(p, "anisotropic", 1, {0.f});
+        } else if (type == "glass") { // glass.cpp:189-196,216-233
+            m.type = VMK_MAT_GLASS;
+            m.slot[0] = parse_slot(p, "color", 3, {1, 1, 1});
+            std::string gname = p["material_name"].as_string();
+            if (gname.empty()) m.slot[1] = parse_slot(p, "ior", 1, {1.5f});
+            else { // Sellmeier at rgb_spectrum_peak_wavelengths.x (glass.cpp:104-134,226-228)
+                float lambda = 602.785f / 1000.f; float l2 = lambda * lambda, f;
+                if (gname == "LASF9") f = 2.00029547f * l2 / (l2 - 0.0121426017f) + 0.298926886f * l2 / (l2 - 0.0538736236f) + 1.80691843f * l2 / (l2 - 156.530829f);
+                else f = 1.03961212f * l2 / (l2 - 0.00600069867f) + 0.231792344f * l2 / (l2 - 0.0200179144f) + 1.01046945f * l2 / (l2 - 103.560653f);
+                m.slot[1].v[0] = std::sqrt(f + 1.f);
+            }
+            m.slot[2] = parse_slot(p, "roughness", 1, {0.5f}); m.slot[3] = parse_slot(p, "anisotropic", 1, {0.f});
+        } else if (type == "substrate") { // substrate.cpp:117-124
+            m.type = VMK_MAT_SUBSTRATE;
+            m.slot[0] = parse_slot(p, "color", 3, {1, 1, 1}); m.slot[1] = parse_slot(p, "spec", 3, {0.05f, 0.05f, 0.05f});
+            m.slot[2] = parse_slot(p, "roughness", 1, {0.5f}); m.slot[3] = parse_slot(p, "anisotropic", 1, {0.f});
+        } else if (type == "principled_bsdf") { // principled_bsdf.cpp:281-307
+            m.type = VMK_MAT_PRINCIPLED;
+            m.slot[VMK_P_COLOR] = parse_slot(p, "color", 3, {1, 1, 1}); m.slot[VMK_P_METALLIC] = parse_slot(p, "metallic", 1, {0.f});
+            m.slot[VMK_P_IOR] = parse_slot(p, "ior", 1, {1.5f}); m.slot[VMK_P_ROUGHNESS] = parse_slot(p, "roughness", 1, {0.5f});
+            m.slot[VMK_P_SPEC_TINT] = parse_slot(p, "spec_tint", 3, {1, 1, 1}); m.slot[VMK_P_ANISOTROPIC] = parse_slot(p, "anisotropic", 1, {0.f});
+            m.slot[VMK_P_OPACITY] = parse_slot(p, "opcacity", 1, {1.f});
+            m.slot[VMK_P_SHEEN_WEIGHT] = parse_slot(p, "sheen_weight", 1, {0.f}); m.slot[VMK_P_SHEEN_ROUGHNESS] = parse_slot(p, "sheen_roughness", 1, {0.5f});
+            m.slot[VMK_P_SHEEN_TINT] = parse_slot(p, "sheen_tint", 3, {1, 1, 1});
+            m.slot[VMK_P_COAT_WEIGHT] = parse_slot(p, "coat_weight", 1, {0.f}); m.slot[VMK_P_COAT_ROUGHNESS] = parse_slot(p, "coat_roughness", 1, {0.2f});
+            m.slot[VMK_P_COAT_IOR] = parse_slot(p, "coat_ior", 1, {1.5f}); m.slot[VMK_P_COAT_TINT] = parse_slot(p, "coat_tint", 3, {1, 1, 1});
+            m.slot[VMK_P_SSS_WEIGHT] = parse_slot(p, "subsurface_weight", 1, {0.3f}); m.slot[VMK_P_SSS_RADIUS] = parse_slot(p, "subsurface_radius", 3, {1, 1, 1});
+            m.slot[VMK_P_SSS_SCALE] = parse_slot(p, "subsurface_scale", 1, {0.2f}); m.slot[VMK_P_TRANS_WEIGHT] = parse_slot(p, "transmission_weight", 1, {0.f});
+        } else if (type == "mix") { // mix.cpp:27-41
+            m.type = VMK_MAT_MIX;
+            uint32_t c0 = add_material(p["mat0"]), c1 = add_material(p["mat1"]);
+            if (materials[c0].type == VMK_MAT_MIX || materials[c1].type == VMK_MAT_MIX) fail("material '" + name + "': nested mix is outside the hot-path scope");
+            m.child0 = c0; m.child1 = c1;
+            m.slot[0] = parse_slot(p, "frac", 1, {0.5f});
+        } else fail("material type '" + type + "' (" + name + ") is outside the hot-path scope (SURVEY.md §2)");
+        describe("material", type, name);
+        materials.push_back(m);
+        material_names.push_back(name);
+        return (uint32_t) materials.size() - 1;
+    }
+
+    // ---- meshes ----
+    struct Vtx { float p[3], n[3], uv[2]; };
+    struct Mesh { std::vector<Vtx> v; std::vector<uint32_t> idx; };
+
+    static Mesh make_quad(const Json &p) { // quad.cpp:21-50
+        Mesh m; float w = p["width"].as_float(1.f) / 2, h = p["height"].as_float(1.f) / 2;
+        float P[4][3] = {{w, 0, h}, {w, 0, -h}, {-w, 0, h}, {-w, 0, -h}};
+        float UV[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
+        float dp02[3] = {P[0][0] - P[2][0], P[0][1] - P[2][1], P[0][2] - P[2][2]}, dp12[3] = {P[1][0] - P[2][0], P[1][1] - P[2][1], P[1][2] - P[2][2]};
+        float ng[3] = {dp02[1] * dp12[2] - dp02[2] * dp12[1], dp02[2] * dp12[0] - dp02[0] * dp12[2], dp02[0] * dp12[1] - dp02[1] * dp12[0]};
+        for (int i = 0; i < 4; ++i) { Vtx v{}; std::memcpy(v.p, P[i], 12); std::memcpy(v.n, ng, 12); std::memcpy(v.uv, UV[i], 8); m.v.push_back(v); }
+        m.idx = {0, 1, 2, 2, 1, 3};
+        return m;
+    }
+    static Mesh make_cube(const Json &p) { // cube.cpp:21-72
+        float x = p["x"].as_float(1.f), y = p["y"].as_float(1.f), z = p["z"].as_float(1.f);
+        y = y == 0 ? x : y; z = z == 0 ? y : z; x /= 2.f; y /= 2.f; z /= 2.f;
+        const float P[24][3] = {{-x, -y, z}, {x, -y, z}, {-x, y, z}, {x, y, z}, {-x, y, -z}, {x, y, -z}, {-x, -y, -z}, {x, -y, -z},
+                                {-x, y, z}, {x, y, z}, {-x, y, -z}, {x, y, -z}, {-x, -y, z}, {x, -y, z}, {-x, -y, -z}, {x, -y, -z},
+                                {x, -y, z}, {x, y, z}, {x, y, -z}, {x, -y, -z}, {-x, -y, z}, {-x, y, z}, {-x, y, -z}, {-x, -y, -z}};
+        const float N[6][3] = {{0, 0, 1}, {0, 0, -1}, {0, 1, 0}, {0, -1, 0}, {1, 0, 0}, {-1, 0, 0}};
+        const float UV[24][2] = {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {0, 1}, {1, 1}, {0, 0}, {1, 0}, {0, 1}, {1, 1}, {0, 0}, {1, 0},
+                                 {0, 1}, {1, 1}, {0, 0}, {1, 0}, {0, 1}, {1, 1}, {1, 0}, {0, 0}, {0, 1}, {1, 1}, {1, 0}, {0, 0}};
+        Mesh m;
+        for (int i = 0; i < 24; ++i) { Vtx v{}; std::memcpy(v.p, P[i], 12); std::memcpy(v.n, N[i / 4], 12); std::memcpy(v.uv, UV[i], 8); m.v.push_back(v); }
+        m.idx = {0, 1, 3, 0, 3, 2, 6, 5, 7, 4, 5, 6, 10, 9, 11, 8, 9, 10, 13, 14, 15, 13, 12, 14, 18, 17, 19, 17, 16, 19, 21, 22, 23, 20, 21, 23};
+        return m;
+    }
+    // Wavefront OBJ (model.cpp:23-36 -> AssimpParser, importers/assimp_parser.cpp:231-341): unique vertex per distinct
+    // (v, vt, vn) triple in first-use order (aiProcess_JoinIdenticalVertices), polygons fan-triangulated
+    // (assimp_parser.cpp:284-295), flip_uv (v -> 1-v, default true), flat normals when the file has none.
+    Mesh load_obj(const std::string &path, bool flip_uv, bool smooth) {
+        std::ifstream f(path);
+        if (!f) fail("cannot open mesh '" + path + "'");
+        std::vector<std::array<float, 3>> P, N; std::vector<std::array<float, 2>> T;
+        Mesh m; std::map<std::array<int, 3>, uint32_t> uniq;
+        std::string line;
+        bool gen_normals = false;
+        std::vector<std::array<int, 3>> poly;
+        while (std::getline(f, line)) {
+            const char *s = line.c_str();
+            while (*s == ' ' || *s == '\t') ++s;
+            if (s[0] == 'v' && s[1] == ' ') { std::array<float, 3> v{}; std::sscanf(s + 2, "%f %f %f", &v[0], &v[1], &v[2]); P.push_back(v); }
+            else if (s[0] == 'v' && s[1] == 'n') { std::array<float, 3> v{}; std::sscanf(s + 3, "%f %f %f", &v[0], &v[1], &v[2]); N.push_back(v); }
+            else if (s[0] == 'v' && s[1] == 't') { std::array<float, 2> v{}; std::sscanf(s + 3, "%f %f", &v[0], &v[1]); T.push_back(v); }
+            else if (s[0] == 'f' && s[1] == ' ') {
+                poly.clear();
+                const char *q = s + 2;
+                while (*q) {
+                    while (*q == ' ' || *q == '\t' || *q == '\r') ++q;
+                    if (!*q) break;
+                    int vi = 0, ti = 0, ni = 0; char *e;
+                    vi = (int) std::strtol(q, &e, 10); q = e;
+                    if (*q == '/') { ++q; if (*q != '/') { ti = (int) std::strtol(q, &e, 10); q = e; } if (*q == '/') { ++q; ni = (int) std::strtol(q, &e, 10); q = e; } }
+                    if (vi < 0) vi = (int) P.size() + vi + 1;
+                    if (ti < 0) ti = (int) T.size() + ti + 1;
+                    if (ni < 0) ni = (int) N.size() + ni + 1;
+                    poly.push_back({vi, ti, ni});
+                }
+                if (poly.size() < 3) continue;
+                for (size_t k = 1; k + 1 < poly.size(); ++k) {
+                    std::array<int, 3> tri[3] = {poly[0], poly[k], poly[k + 1]};
+                    if (tri[0][0] == tri[1][0] || tri[1][0] == tri[2][0] || tri[0][0] == tri[2][0]) continue; // aiProcess_FindDegenerates
+                    for (auto &c : tri) {
+                        std::array<int, 3> key = c;
+                        if (key[2] == 0) { gen_normals = true; key[2] = -(int) (m.idx.size() / 3) - 1; } // flat: unique per face
+                        auto it = uniq.find(key);
+                        uint32_t id;
+                        if (it == uniq.end()) {
+                            Vtx v{};
+                            if (c[0] < 1 || c[0] > (int) P.size()) fail("bad vertex index in '" + path + "'");
+                            std::memcpy(v.p, P[c[0] - 1].data(), 12);
+                            if (c[2] >= 1 && c[2] <= (int) N.size()) std::memcpy(v.n, N[c[2] - 1].data(), 12);
+                            if (c[1] >= 1 && c[1] <= (int) T.size()) { v.uv[0] = T[c[1] - 1][0]; v.uv[1] = flip_uv ? 1.f - T[c[1] - 1][1] : T[c[1] - 1][1]; }
+                            for (float &x : v.n) if (!std::isfinite(x)) { v.n[0] = v.n[1] = v.n[2] = 0.f; break; }
+                            for (float &x : v.uv) if (!std::isfinite(x)) { v.uv[0] = v.uv[1] = 0.f; break; }
+                            id = (uint32_t) m.v.size(); m.v.push_back(v); uniq[key] = id;
+                        } else id = it->second;
+                        m.idx.push_back(id);
+                    }
+                }
+            }
+        }
+        if (gen_normals) { // aiProcess_GenNormals
+            (void) smooth;
+            for (size_t t = 0; t + 2 < m.idx.size(); t += 3) {
+                Vtx &a = m.v[m.idx[t]], &b = m.v[m.idx[t + 1]], &c = m.v[m.idx[t + 2]];
+                float e1[3] = {b.p[0] - a.p[0], b.p[1] - a.p[1], b.p[2] - a.p[2]}, e2[3] = {c.p[0] - a.p[0], c.p[1] - a.p[1], c.p[2] - a.p[2]};
+                float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                if (l > 0) for (float &x : n) x /= l;
+                for (Vtx *v : {&a, &b, &c}) if (v->n[0] == 0 && v->n[1] == 0 && v->n[2] == 0) std::memcpy(v->n, n, 12);
+            }
+        }
+        return m;
+    }
+
+    // float32 o2w.apply_point exactly as compute_surface_interaction evaluates it per hit (geometry.cpp:94-96)
+    static void apply_point(const float *o2w, const float *p, float *out) {
+        for (int r = 0; r < 3; ++r) out[r] = o2w[0 * 4 + r] * p[0] + o2w[1 * 4 + r] * p[1] + o2w[2 * 4 + r] * p[2] + o2w[3 * 4 + r];
+    }
+    uint32_t add_instance(const Mesh &mesh, const Mat4 &o2w, uint32_t mat_id) {
+        vmk_instance inst{};
+        inst.mat_id = mat_id; inst.light_id = VMK_INVALID;
+        inst.tri_offset = (uint32_t) tri_pos.size(); inst.tri_count = (uint32_t) (mesh.idx.size() / 3);
+        for (int i = 0; i < 16; ++i) inst.o2w[i] = (float) o2w.m[i];
+        Mat4 inv = inverse(o2w); // normal matrix = transpose(inverse(M3x3)): n2w(row r, col c) = inv(c, r)
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) inst.n2w[c * 3 + r] = (float) inv.at(c, r);
+        uint32_t inst_id = (uint32_t) instances.size();
+        for (uint32_t t = 0; t < inst.tri_count; ++t) {
+            const Vtx &a = mesh.v[mesh.idx[3 * t]], &b = mesh.v[mesh.idx[3 * t + 1]], &c = mesh.v[mesh.idx[3 * t + 2]];
+            vmk_tri_pos tp{}; vmk_tri_attr ta{};
+            apply_point(inst.o2w, a.p, tp.p0); apply_point(inst.o2w, b.p, tp.p1); apply_point(inst.o2w, c.p, tp.p2);
+            tp.inst = inst_id; tp.prim = t;
+            std::memcpy(ta.n0, a.n, 12); std::memcpy(ta.n1, b.n, 12); std::memcpy(ta.n2, c.n, 12);
+            std::memcpy(ta.uv0, a.uv, 8); std::memcpy(ta.uv1, b.uv, 8); std::memcpy(ta.uv2, c.uv, 8);
+            for (const float *pp : {tp.p0, tp.p1, tp.p2}) for (int k = 0; k < 3; ++k) { bmin[k] = std::min(bmin[k], (double) pp[k]); bmax[k] = std::max(bmax[k], (double) pp[k]); }
+            tri_pos.push_back(tp); tri_attr.push_back(ta);
+        }
+        instances.push_back(inst);
+        return inst_id;
+    }
+    uint32_t append_alias(const AliasBuild &a) {
+        uint32_t off = (uint32_t) alias_prob.size();
+        alias_prob.insert(alias_prob.end(), a.prob.begin(), a.prob.end());
+        alias_idx.insert(alias_idx.end(), a.alias.begin(), a.alias.end());
+        alias_func.insert(alias_func.end(), a.func.begin(), a.func.end());
+        return off;
+    }
+
+    // Light::Light + initialize_slots (light.cpp:10-24): colour normalised so max component <= 1, factor folded into scale
+    void init_light_color(vmk_light &l, const Json &p, bool env) {
+        l.scale = p["scale"].as_float(1.f);
+        l.color = parse_slot(p, "color", 3, {0.5f, 0.5f, 0.5f}, env);
+        if (l.color.tex == VMK_INVALID) { // NumberArray::normalize (number.cpp:38-47)
+            float mx = std::max(l.color.v[0], std::max(l.color.v[1], l.color.v[2]));
+            if (!(mx < 1.f)) { for (float &c : l.color.v) c = c / mx; l.scale = l.scale * mx; }
+        }
+    }
+
+    void load(const std::string &json_path) {
+        std::ifstream f(json_path);
+        if (!f) fail("cannot open scene '" + json_path + "'");
+        std::stringstream ss; ss << f.rdbuf();
+        Json root;
+        try { root = Json::parse(ss.str()); } catch (std::exception &e) { fail(std::string("scene json: ") + e.what()); }
+        scene_dir = dir_of(json_path);
+
+        // ---- render_setting / spectrum / mediums (scene_desc.cpp:37-53, node_desc.cpp:371-376) ----
+        const Json &rs = root["render_setting"];
+        params.ray_offset_factor = rs["ray_offset_factor"].as_float(1.f);
+        double min_world_radius = rs["min_world_radius"].as_double(10.0);
+        const Json &spec = root["spectrum"];
+        std::string spec_type = spec["type"].as_string("srgb");
+        if (spec_type != "srgb") fail("spectrum/" + spec_type + " is a §8(f) 'next' row (needs the stripped srgb2spec table); only spectrum/srgb is in scope");
+        if (spec["param"]["dimension"].as_uint(3) != 3) fail("spectrum/srgb requires dimension 3");
+        describe("spectrum", "srgb", "");
+        if (root["mediums"]["process"].as_bool(false)) describe("medium", "ignored", "mediums.process=true is a §8(f) 'next' row; rendered as the non-fog variant");
+
+        // ---- materials ----
+        for (auto &md : root["materials"].arr) add_material(md);
+
+        // ---- light_sampler descs first (lights listed in JSON precede shape emissions: LightSampler ctor lightsampler.cpp:15-27) ----
+        const Json &lsd = root["light_sampler"];
+        std::string ls_type = lsd["type"].as_string("uniform");
+        if (ls_type != "uniform") fail("lightsampler/" + ls_type + " is outside the hot-path scope (uniform only)");
+        describe("lightsampler", "uniform", "");
+        params.env_separate = lsd["param"]["env_separate"].as_bool(false) ? 1u : 0u;
+        params.env_prob = std::min(0.99f, std::max(0.01f, lsd["param"]["env_prob"].as_float(0.5f)));
+        struct PendingLight { vmk_light l; int order; };
+        std::vector<PendingLight> pending;
+        for (auto &ld : lsd["param"]["lights"].arr) {
+            std::string type = ld["type"].as_string("area");
+            const Json &p = ld["param"];
+            if (type == "spherical") { // spherical.cpp:33-44
+                vmk_light l{}; l.type = VMK_LIGHT_SPHERICAL; l.inst_id = VMK_INVALID;
+                init_light_color(l, p, true);
+                bool flip_u = p["flip_u"].as_bool(false);
+                Mat4 o2w = parse_transform(p["o2w"]) * (rotation_x(-90) * scale(1.0, flip_u ? 1.0 : -1.0, 1.0));
+                Mat4 w2o = inverse(o2w);
+                Mat4 w2o_f{}; for (int i = 0; i < 16; ++i) w2o_f.m[i] = (double) (float) w2o.m[i];
+                Mat4 o2w_back = inverse(w2o_f); // spherical.cpp:114 evaluates inverse(*w2o_) per sample
+                for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) { l.w2o[c * 3 + r] = (float) w2o.at(r, c); l.o2w[c * 3 + r] = (float) o2w_back.at(r, c); }
+                pending.push_back({l, 1});
+                describe("light", "spherical", ld["name"].as_string());
+            } else if (type == "area") {
+                fail("stand-alone light/area (own quad geometry, area.cpp:56-71) is outside the hot-path scope; use shape.param.emission");
+            } else {
+                if (opt.drop_unsupported_lights) { describe("light", type, "DROPPED (outside hot-path scope)"); continue; }
+                fail("light/" + type + " is outside the hot-path scope (area + spherical; point/spot are §8(f) 'next')");
+            }
+        }
+
+        // ---- shapes (Scene::load_shapes / add_shape scene.cpp:120-163) ----
+        for (auto &sd : root["shapes"].arr) {
+            std::string type = sd["type"].as_string();
+            const Json &p = sd["param"];
+            Mesh mesh;
+            if (type == "quad") mesh = make_quad(p);
+            else if (type == "cube") mesh = make_cube(p);
+            else if (type == "model") {
+                std::string fn = p["fn"].as_string();
+                if (p["swap_handed"].as_bool(false) || p["subdiv_level"].as_uint(0)) fail("shape/model swap_handed/subdiv_level are outside the hot-path scope");
+                if (!ends_with(fn, ".obj")) fail("shape/model: only Wavefront .obj is supported ('" + fn + "')");
+                mesh = list_only ? Mesh{} : load_obj(join_path(scene_dir, fn), p["flip_uv"].as_bool(true), p["smooth"].as_bool(false));
+            } else fail("shape/" + type + " is outside the hot-path scope (quad/cube/model)");
+            describe("shape", type, sd["name"].as_string());
+            std::string mat_name = p["material"].as_string();
+            uint32_t mat_id = VMK_INVALID;
+            for (uint32_t i = 0; i < material_names.size(); ++i) if (material_names[i] == mat_name) { mat_id = i; break; } // find_if: first match
+            uint32_t inst_id = add_instance(mesh, parse_transform(p["transform"]), mat_id);
+            if (p.contains("emission")) { // ShapeDesc::init node_desc.cpp:66-68 -> light/area with inst_id
+                const Json &em = p["emission"];
+                std::string etype = em["type"].as_string("area");
+                if (etype != "area") fail("emission type '" + etype + "' unsupported");
+                vmk_light l{}; l.type = VMK_LIGHT_AREA; l.inst_id = inst_id;
+                init_light_color(l, em["param"], false);
+                l.two_sided = em["param"]["two_sided"].as_bool(false) ? 1u : 0u;
+                pending.push_back({l, 0});
+                describe("light", "area", sd["name"].as_string());
+            }
+        }
+
+        // ---- LightSampler::tidy_up: lights grouped by topology (type) in first-seen order (lightsampler.cpp:64-74) ----
+        {
+            std::vector<uint32_t> first_seen; // type order of first appearance
+            auto topo = [](const vmk_light &l) { return l.type * 2u + (l.color.tex != VMK_INVALID ? 1u : 0u); };
+            for (auto &pl : pending) { uint32_t t = topo(pl.l); if (std::find(first_seen.begin(), first_seen.end(), t) == first_seen.end()) first_seen.push_back(t); }
+            std::stable_sort(pending.begin(), pending.end(), [&](const PendingLight &a, const PendingLight &b) {
+                auto ia = std::find(first_seen.begin(), first_seen.end(), topo(a.l)) - first_seen.begin();
+                auto ib = std::find(first_seen.begin(), first_seen.end(), topo(b.l)) - first_seen.begin();
+                return ia < ib;
+            });
+        }
+        double ext[3] = {bmax[0] - bmin[0], bmax[1] - bmin[1], bmax[2] - bmin[2]};
+        double aabb_radius = tri_pos.empty() ? 0.0 : 0.5 * std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
+        float world_diameter = (float) (std::max(aabb_radius, min_world_radius) * 2.0); // scene.h:108-109
+        scene.env_light = VMK_INVALID;
+        for (auto &pl : pending) {
+            vmk_light l = pl.l;
+            uint32_t light_id = (uint32_t) lights.size();
+            if (l.type == VMK_LIGHT_AREA) { // AreaLight::prepare (area.cpp:170-176): alias table over triangle areas
+                vmk_instance &inst = instances[l.inst_id];
+                inst.light_id = light_id;
+                std::vector<float> areas;
+                for (uint32_t t = 0; t < inst.tri_count; ++t) {
+                    const vmk_tri_pos &tp = tri_pos[inst.tri_offset + t];
+                    float e1[3] = {tp.p1[0] - tp.p0[0], tp.p1[1] - tp.p0[1], tp.p1[2] - tp.p0[2]}, e2[3] = {tp.p2[0] - tp.p0[0], tp.p2[1] - tp.p0[1], tp.p2[2] - tp.p0[2]};
+                    float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                    areas.push_back(0.5f * std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]));
+                }
+                if (areas.empty()) fail("emissive shape without triangles");
+                AliasBuild a = build_alias(areas);
+                l.alias_offset = append_alias(a); l.alias_count = (uint32_t) areas.size(); l.alias_integral = a.integral;
+            } else { // SphericalMap::prepare (spherical.cpp:198-212) + AliasTable2D::build (alias2d.cpp:32-68)
+                scene.env_light = light_id;
+                l.world_diameter = world_diameter;
+                uint32_t rx = 1, ry = 1; std::vector<float> weights;
+                if (l.color.tex == VMK_INVALID || list_only) weights.push_back(1.f);
+                else { // calculate_weights (spherical.cpp:170-196) incl. its `v = idx / res.y + 0.5; theta = v / res.x` quirk
+                    const vmk_texture &t = textures[l.color.tex & 0xffffu];
+                    rx = t.width; ry = t.height; weights.resize((size_t) rx * ry);
+                    for (uint32_t idx = 0; idx < rx * ry; ++idx) {
+                        float v = (float) (idx / ry) + 0.5f;
+                        float theta = v / (float) rx;
+                        float sinTheta = std::sin(3.14159265358979323846f * theta);
+                        float lum;
+                        if (t.format == VMK_TEX_RGBA32F) { const float *px = (const float *) (tex_data.data() + t.offset) + (size_t) idx * 4; lum = 0.212671f * px[0] + 0.715160f * px[1] + 0.072169f * px[2]; }
+                        else { const uint8_t *px = tex_data.data() + t.offset + (size_t) idx * 4; lum = 0.212671f * (px[0] / 255.f) + 0.715160f * (px[1] / 255.f) + 0.072169f * (px[2] / 255.f); }
+                        weights[idx] = lum * sinTheta;
+                    }
+                }
+                std::vector<float> marginal; std::vector<AliasBuild> rows;
+                for (uint32_t v = 0; v < ry; ++v) { rows.push_back(build_alias(std::vector<float>(weights.begin() + (size_t) v * rx, weights.begin() + (size_t) (v + 1) * rx))); marginal.push_back(rows.back().integral); }
+                AliasBuild mg = build_alias(marginal);
+                l.alias_offset = append_alias(mg); l.alias_count = ry; l.alias_integral = mg.integral;
+                l.cond_offset = (uint32_t) alias_prob.size();
+                for (auto &r : rows) append_alias(r);
+                l.res_x = rx; l.res_y = ry;
+            }
+            lights.push_back(l);
+        }
+        if (lights.empty() && !list_only) fail("scene has no light inside the hot-path scope (area / spherical)");
+
+        // ---- sensor (sensor.cpp:17-25,58-78,153-162; thin_lens.cpp:16-20) ----
+        const Json &cam = root["camera"];
+        std::string cam_type = cam["type"].as_string("thin_lens");
+        if (cam_type != "thin_lens" && cam_type != "pinhole") fail("sensor/" + cam_type + " is outside the hot-path scope");
+        describe("sensor", cam_type, cam["param"]["name"].as_string());
+        const Json &cp = cam["param"];
+        const Json &fbp = root["pipeline"]["param"]["frame_buffer"]["param"];
+        uint32_t W = 1280, H = 720; // frame_buffer.cpp:18 default
+        if (fbp["resolution"].is_array() && fbp["resolution"].size() == 2) { W = fbp["resolution"].at(0).as_uint(W); H = fbp["resolution"].at(1).as_uint(H); }
+        if (opt.width && opt.height) { W = opt.width; H = opt.height; }
+        params.width = W; params.height = H;
+        {
+            double fov_y = std::min(120.0, std::max(15.0, cp["fov_y"].as_double(20.0))); // sensor.h:20-21,99-111
+            Mat4 m = parse_transform(cp["transform"]);
+            double pitch = std::atan2(m.at(2, 1), m.at(1, 1)) * 180.0 / M_PI; // m[1][2], m[1][1]
+            double yaw = std::atan2(m.at(0, 2), m.at(0, 0)) * 180.0 / M_PI;   // m[2][0], m[0][0]
+            Mat4 c2w = translation(m.at(0, 3), m.at(1, 3), m.at(2, 3)) * (scale(1, 1, -1) * rotation_y(yaw) * rotation_x(-pitch));
+            for (int i = 0; i < 16; ++i) params.c2w[i] = (float) c2w.m[i];
+            // FrameBuffer::update_screen_window (frame_buffer.cpp:93-102), Sensor::update_resolution / update_raster
+            double ratio = (double) W / (double) H;
+            double lx = -1, ux = 1, ly = -1, uy = 1;
+            if (ratio > 1.0) { lx = -ratio; ux = ratio; } else { ly = -1.0 / ratio; uy = 1.0 / ratio; }
+            Mat4 screen_to_raster = scale(W, H, 1) * scale(1.0 / (ux - lx), 1.0 / -(uy - ly), 1.0) * translation(-lx, -uy, 0.0);
+            double n = 0.01, fz = 1000.0, inv_tan = 1.0 / std::tan(radians(fov_y) / 2.0);
+            Mat4 persp{}; persp.at(0, 0) = 1; persp.at(1, 1) = 1; persp.at(2, 2) = fz / (fz - n); persp.at(2, 3) = -fz * n / (fz - n); persp.at(3, 2) = 1;
+            Mat4 camera_to_screen = scale(inv_tan, inv_tan, 1) * persp;
+            Mat4 raster_to_sensor = inverse(camera_to_screen) * inverse(screen_to_raster);
+            for (int i = 0; i < 16; ++i) params.raster_to_sensor[i] = (float) raster_to_sensor.m[i];
+            params.focal_distance = cam_type == "thin_lens" ? cp["focal_distance"].as_float(5.f) : 5.f;
+            params.lens_radius = cam_type == "thin_lens" ? cp["lens_radius"].as_float(0.f) : 0.f;
+        }
+        // ---- filter (filter.h:36-39; radius is read as a scalar — an array takes its first element) ----
+        {
+            const Json &fd = cp["filter"];
+            std::string ft = fd["type"].as_string("gaussian");
+            const Json &rj = fd["param"]["radius"];
+            float radius = rj.is_array() ? rj.at(0).as_float(0.5f) : rj.as_float(0.5f);
+            params.filter_radius[0] = params.filter_radius[1] = radius;
+            describe("filter", ft, "");
+            if (ft == "box") params.filter_type = VMK_FILTER_BOX;
+            else if (ft == "triangle") params.filter_type = VMK_FILTER_TRIANGLE;
+            else if (ft == "gaussian") { // gaussian.cpp:20-42 + FilterSampler::build (fitted_curve.h:37-58)
+                params.filter_type = VMK_FILTER_TABLE;
+                float sigma = fd["param"]["sigma"].as_float(1.f);
+                auto gaussian = [](float x, float mu, float sg) { return 1.f / std::sqrt(2 * 3.14159265358979323846f * sg * sg) * std::exp(-(x - mu) * (x - mu) / (2 * sg * sg)); };
+                float ex = gaussian(radius, 0, sigma);
+                const int N = VMK_FILTER_TABLE_SIZE;
+                std::vector<float> func((size_t) N * N);
+                for (int i = 0; i < N * N; ++i) {
+                    int x = i % N, y = i / N;
+                    float px = (x + 0.5f) / N * radius, py = (y + 0.5f) / N * radius;
+                    float val = std::max(0.f, gaussian(px, 0, sigma) - ex) * std::max(0.f, gaussian(py, 0, sigma) - ex);
+                    func[i] = std::fabs(val);
+                }
+                std::vector<float> marginal; std::vector<AliasBuild> rows;
+                for (int v = 0; v < N; ++v) { rows.push_back(build_alias(std::vector<float>(func.begin() + v * N, func.begin() + (v + 1) * N))); marginal.push_back(rows.back().integral); }
+                AliasBuild mg = build_alias(marginal);
+                for (int v = 0; v < N; ++v) {
+                    params.filter_marginal_prob[v] = mg.prob[v]; params.filter_marginal_alias[v] = mg.alias[v]; params.filter_marginal_func[v] = mg.func[v];
+                    for (int u = 0; u < N; ++u) { params.filter_cond_prob[v * N + u] = rows[v].prob[u]; params.filter_cond_alias[v * N + u] = rows[v].alias[u]; params.filter_cond_func[v * N + u] = rows[v].func[u]; }
+                }
+                params.filter_marginal_integral = mg.integral;
+            } else fail("filter/" + ft + " is a §8(f) 'next' row (box/triangle/gaussian in scope)");
+        }
+        // ---- integrator (integrator.cpp:59-66) ----
+        {
+            const Json &ig = root["integrator"];
+            std::string it = ig["type"].as_string("pt");
+            if (it != "pt") fail("integrator/" + it + " is outside the hot-path scope (pt only)");
+            describe("integrator", "pt", "");
+            const Json &ip = ig["param"];
+            params.max_depth = ip["max_depth"].as_uint(16); params.min_depth = ip["min_depth"].as_uint(5);
+            params.rr_threshold = ip["rr_threshold"].as_float(1.f); params.mis_mode = (uint32_t) ip["mis_mode"].as_int(0);
+            if (ip["separate"].as_bool(false)) describe("integrator", "pt", "note: separate=true has identical arithmetic on this backend");
+            if (opt.max_depth >= 0) params.max_depth = (uint32_t) opt.max_depth;
+            if (opt.min_depth >= 0) params.min_depth = (uint32_t) opt.min_depth;
+        }
+        std::string samp = root["sampler"]["type"].as_string("independent");
+        if (samp != "independent") fail("sampler/" + samp + " is outside the hot-path scope");
+        describe("sampler", "independent", "");
+        // ---- frame buffer / tone mapper / output (frame_buffer.cpp:15-26, node_desc.cpp:214-220,360-369) ----
+        params.exposure = fbp["exposure"].as_float(1.f);
+        std::string tm = fbp["tone_mapper"]["type"].as_string("linear");
+        params.tone_mapper = tm == "aces" ? 1u : (tm == "reinhard" ? 2u : 0u);
+        describe("pipeline", root["pipeline"]["type"].as_string("fixed"), "");
+        describe("framebuffer", "normal", "");
+        describe("tonemapper", tm, "");
+        output_spp = root["output"]["spp"].as_uint(0);
+        output_fn = root["output"]["fn"].as_string("output.png");
+    }
+
+    void load_luts() {
+        std::string path = opt.lut_path ? opt.lut_path : "";
+        if (path.empty()) fail("vmk_host_options.lut_path not set (albedo tables, vision_amd/data/luts.bin)");
+        std::ifstream f(path, std::ios::binary);
+        if (!f) fail("cannot open albedo-table blob '" + path + "' (generate with tools/make_luts.py)");
+        // header: magic 'VLUT', version, counts[7] (floats per table; 0 = absent)
+        uint32_t hdr[9];
+        f.read((char *) hdr, sizeof(hdr));
+        if (!f || hdr[0] != 0x54554c56u || hdr[1] != 1u) fail("bad albedo-table blob '" + path + "'");
+        const uint32_t N = VMK_LUT_RES;
+        const uint32_t expect[7] = {N * N, N * N * N * 2, N * N * N * 2, N * N * N, N * N * N, N * N * 4, N * N * 4};
+        size_t total = 0;
+        for (int i = 0; i < 7; ++i) { if (hdr[2 + i] != 0 && hdr[2 + i] != expect[i]) fail("albedo-table blob: unexpected size"); total += hdr[2 + i]; }
+        luts.resize(total);
+        f.read((char *) luts.data(), (std::streamsize) (total * 4));
+        if (!f) fail("albedo-table blob truncated");
+        const float **dst[7] = {&scene.luts.pure_reflection, &scene.luts.dielectric, &scene.luts.dielectric_inv, &scene.luts.specular, &scene.luts.coat, &scene.luts.sheen_approx, &scene.luts.sheen_volume};
+        size_t off = 0;
+        for (int i = 0; i < 7; ++i) { *dst[i] = hdr[2 + i] ? luts.data() + off : nullptr; off += hdr[2 + i]; }
+        for (int i = 0; i < 5; ++i) if (!*dst[i]) fail("albedo-table blob lacks a required table");
+    }
+
+    void finalize() {
+        scene.abi_version = VMK_ABI_VERSION;
+        scene.n_tris = (uint32_t) tri_pos.size(); scene.n_instances = (uint32_t) instances.size(); scene.n_materials = (uint32_t) materials.size();
+        scene.n_lights = (uint32_t) lights.size(); scene.n_textures = (uint32_t) textures.size(); scene.n_alias = (uint32_t) alias_prob.size();
+        scene.tri_pos = tri_pos.data(); scene.tri_attr = tri_attr.data(); scene.instances = instances.data(); scene.materials = materials.data();
+        scene.lights = lights.data(); scene.textures = textures.data(); scene.tex_data = tex_data.data(); scene.tex_bytes = tex_data.size();
+        scene.alias_prob = alias_prob.data(); scene.alias_idx = alias_idx.data(); scene.alias_func = alias_func.data();
+        for (int k = 0; k < 3; ++k) { scene.world_min[k] = (float) bmin[k]; scene.world_max[k] = (float) bmax[k]; }
+        // sheen needs the LTC tables; without them only sheen_weight == 0 (constant) is accepted
+        if (!scene.luts.sheen_approx)
+            for (auto &m : materials) if (m.type == VMK_MAT_PRINCIPLED && (m.slot[VMK_P_SHEEN_WEIGHT].tex != VMK_INVALID || m.slot[VMK_P_SHEEN_WEIGHT].v[0] != 0.f))
+                fail("principled_bsdf with sheen_weight != 0 needs the LTC sheen tables (absent from the albedo-table blob)");
+    }
+};
+
+}// namespace vmk
+
+using namespace vmk;
+
+struct vmk_host_scene { HostScene hs; };
+
+extern "C" {
+
+const char *vmk_host_last_error(void) { return g_error.c_str(); }
+
+int vmk_host_register_image(const char *path, uint32_t width, uint32_t height, uint32_t channels, int is_float, const void *pixels) {
+    if (!path || !pixels || !width || !height || channels < 1 || channels > 4) { g_error = "vmk_host_register_image: bad argument"; return VMK_ERR_ARG; }
+    Image img; img.w = width; img.h = height; img.channels = channels; img.is_float = is_float != 0;
+    size_t n = (size_t) width * height * channels;
+    if (is_float) img.f32.assign((const float *) pixels, (const float *) pixels + n);
+    else img.u8.assign((const uint8_t *) pixels, (const uint8_t *) pixels + n);
+    g_images[path] = std::move(img);
+    return VMK_OK;
+}
+void vmk_host_clear_images(void) { g_images.clear(); }
+
+int vmk_host_list_images(const char *json_path, char *buf, uint32_t buf_bytes) {
+    try {
+        HostScene hs; hs.list_only = true; hs.opt.procedural_env = 1; hs.opt.drop_unsupported_lights = 1;
+        hs.load(json_path);
+        std::string out;
+        for (auto &p : hs.image_paths) out += p + "\n";
+        if (out.size() + 1 > buf_bytes) { g_error = "vmk_host_list_images: buffer too small"; return VMK_ERR_ARG; }
+        std::memcpy(buf, out.c_str(), out.size() + 1);
+        return (int) out.size();
+    } catch (std::exception &e) { g_error = e.what(); return VMK_ERR_UNSUPPORTED; }
+}
+
+int vmk_host_load_scene(const char *json_path, const vmk_host_options *opt, vmk_host_scene **out) {
+    if (!json_path || !out) { g_error = "vmk_host_load_scene: bad argument"; return VMK_ERR_ARG; }
+    auto *h = new vmk_host_scene();
+    try {
+        if (opt) h->hs.opt = *opt; else { h->hs.opt.max_depth = -1; h->hs.opt.min_depth = -1; }
+        std::string lut = opt && opt->lut_path ? opt->lut_path : "";
+        h->hs.opt.lut_path = lut.empty() ? nullptr : lut.c_str();
+        h->hs.load_luts();
+        h->hs.load(json_path);
+        h->hs.finalize();
+        h->hs.opt.lut_path = nullptr;
+    } catch (std::exception &e) { g_error = e.what(); delete h; return VMK_ERR_UNSUPPORTED; }
+    *out = h;
+    return VMK_OK;
+}
+void vmk_host_free_scene(vmk_host_scene *scene) { delete scene; }
+const vmk_scene *vmk_host_scene_tables(const vmk_host_scene *scene) { return scene ? &scene->hs.scene : nullptr; }
+const vmk_render_params *vmk_host_render_params(const vmk_host_scene *scene) { return scene ? &scene->hs.params : nullptr; }
+uint32_t vmk_host_output_spp(const vmk_host_scene *scene) { return scene ? scene->hs.output_spp : 0; }
+const char *vmk_host_output_fn(const vmk_host_scene *scene) { return scene ? scene->hs.output_fn.c_str() : ""; }
+const char *vmk_host_describe(const vmk_host_scene *scene) { return scene ? scene->hs.description.c_str() : ""; }
+
+}// extern "C"

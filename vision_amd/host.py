@@ -1,0 +1,116 @@
+"""Python binding of the C++ host (libvmk_host.so): Vision JSON scene -> flat vmk tables.
+
+The host keeps Vision's plugin namespace (category/type) and JSON schema; see include/vmk_host.h.  Image files are
+decoded here with Pillow and handed to the host (Vision decodes through ocarina's Image::load,
+src/base/mgr/image_pool.cpp:23-28); `.hdr` is decoded natively by the host.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+DEFAULT_LUT_PATH = os.path.join(_PKG, "data", "luts.bin")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_PKG, "lib", "libvmk_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(path)
+        L.vmk_host_last_error.restype = C.c_char_p
+        L.vmk_host_scene_tables.restype = C.POINTER(_abi.Scene)
+        L.vmk_host_render_params.restype = C.POINTER(_abi.RenderParams)
+        L.vmk_host_output_fn.restype = C.c_char_p
+        L.vmk_host_describe.restype = C.c_char_p
+        L.vmk_host_output_spp.restype = C.c_uint32
+        L.vmk_host_load_scene.argtypes = [C.c_char_p, C.POINTER(_abi.HostOptions), C.POINTER(C.c_void_p)]
+        L.vmk_host_free_scene.argtypes = [C.c_void_p]
+        for fn in ("vmk_host_scene_tables", "vmk_host_render_params", "vmk_host_output_spp", "vmk_host_output_fn",
+                   "vmk_host_describe"):
+            getattr(L, fn).argtypes = [C.c_void_p]
+        L.vmk_host_register_image.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.vmk_host_list_images.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _err():
+    return lib().vmk_host_last_error().decode()
+
+
+def register_images_for(json_path):
+    """Decode (Pillow) and register every image file the scene references that exists on disk."""
+    L = lib()
+    buf = C.create_string_buffer(1 << 16)
+    n = L.vmk_host_list_images(json_path.encode(), buf, len(buf))
+    if n < 0:
+        raise HostError(_err())
+    paths = [p for p in buf.value.decode().split("\n") if p]
+    for p in paths:
+        if not os.path.exists(p) or p.lower().endswith(".hdr"):
+            continue  # missing (stand-in handled by the host) or natively decoded
+        if p.lower().endswith(".exr"):
+            continue  # no EXR decoder in this image; host falls back to the procedural stand-in if allowed
+        from PIL import Image
+        im = Image.open(p)
+        if im.mode not in ("L", "RGB", "RGBA"):
+            im = im.convert("RGBA" if "A" in im.mode else "RGB")
+        arr = np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+        ch = 1 if arr.ndim == 2 else arr.shape[2]
+        rc = L.vmk_host_register_image(p.encode(), arr.shape[1], arr.shape[0], ch, 0, arr.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise HostError(_err())
+    return paths
+
+
+class HostScene:
+    """Owns the host-side tables of one loaded scene (freed on close())."""
+
+    def __init__(self, json_path, width=0, height=0, max_depth=-1, min_depth=-1, procedural_env=True,
+                 drop_unsupported_lights=False, lut_path=None):
+        L = lib()
+        json_path = os.path.abspath(json_path)
+        self.json_path = json_path
+        self.image_paths = register_images_for(json_path)
+        opt = _abi.HostOptions(width, height, max_depth, min_depth, int(procedural_env), int(drop_unsupported_lights),
+                               (lut_path or DEFAULT_LUT_PATH).encode())
+        h = C.c_void_p()
+        rc = L.vmk_host_load_scene(json_path.encode(), C.byref(opt), C.byref(h))
+        if rc != 0:
+            raise HostError(_err())
+        self._h = h
+        self.tables = L.vmk_host_scene_tables(h)           # POINTER(Scene)
+        self.params = L.vmk_host_render_params(h).contents  # RenderParams (owned by the host scene; mutable copy below)
+        self.output_spp = int(L.vmk_host_output_spp(h))
+        self.output_fn = L.vmk_host_output_fn(h).decode()
+        self.description = L.vmk_host_describe(h).decode()
+
+    @property
+    def scene(self):
+        return self.tables.contents
+
+    def params_copy(self):
+        p = _abi.RenderParams()
+        C.memmove(C.byref(p), C.byref(self.params), C.sizeof(p))
+        return p
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vmk_host_free_scene(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
