@@ -1188,7 +1188,8 @@ inline Ray generate_ray(const vmk_render_params &p, uint32_t px, uint32_t py, Sa
 // =====================================================================================================
 struct PathStats { uint32_t closest{0}, shadow{0}, hits{0}; };
 
-inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sampler) {
+inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sampler, float *dbg = nullptr) {
+    int vtx = 0;
     const vmk_scene *s = sv.s;
     LightCtx lc{s, &p};
     float3 L = make_float3(0.f), T = make_float3(1.f);
@@ -1202,6 +1203,9 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
     };
     for (uint32_t bounces = 0; bounces < p.max_depth; ++bounces) {
         Hit hit = sv.trace_closest(ray);
+        float *rec = (dbg && vtx < 8) ? dbg + 8 * vtx : nullptr;
+        ++vtx;
+        if (rec) { rec[0] = u2f(hit.inst); rec[1] = u2f(hit.prim); rec[2] = hit.bary.x; rec[3] = hit.bary.y; }
         if (hit.is_miss()) { // evaluate_miss
             if (s->env_light != VMK_INVALID) {
                 LightSampleContext p_ref{ray.o, prev_surface_ng};
@@ -1236,6 +1240,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         float3 wi = normalize(ls.p_light - it.pos);
         ScatterEval scatter_eval = evaluator_evaluate(s, lobes, it.ng, it.wo, wi);
         BSDFSample bs = evaluator_sample(s, lobes, it.ng, it.wo, sampler);
+        if (rec) { rec[4] = ls.eval.pdf; rec[5] = scatter_eval.pdf; rec[6] = bs.eval.pdf; rec[7] = occluded ? 1.f : 0.f; }
         bool is_delta_light = ls.eval.pdf < 0.f;
         bool mis = p.mis_mode != 1;
         float weight = mis ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, scatter_eval.pdf)) : 1.f;
@@ -1423,6 +1428,16 @@ int orc_test_eval(void *h, const vmk_render_params *p, uint32_t kind, uint32_t n
                 Sampler s; s.start(f2u(a[0]), f2u(a[1]), f2u(a[2]), 0);
                 Ray r = generate_ray(*p, f2u(a[0]), f2u(a[1]), s);
                 o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+                break;
+            }
+            case 6: { // whole path of one (pixel, frame): 8 floats per vertex (first 8 vertices), then L
+                uint32_t px = f2u(a[0]), py = f2u(a[1]), frame = f2u(a[2]);
+                Sampler s; s.start(px, py, frame, 0);
+                Ray r = generate_ray(*p, px, py, s);
+                s.start(px, py, frame, 1);
+                for (int k = 0; k < 64; ++k) o[k] = 0.f;
+                float3 L = Li(*sv, *p, r, s, o);
+                o[64] = L.x; o[65] = L.y; o[66] = L.z;
                 break;
             }
             default: return -1;

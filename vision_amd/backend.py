@@ -1,0 +1,156 @@
+"""Python binding of libvmk.so (include/vmk.h): the gfx950 megakernel backend.
+
+There is NO CPU fallback: creating a Backend without the HIP library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_PKG, "lib", "libvmk.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise BackendError(f"{path} missing — the HIP extension is not built (run __graft_entry__.build()); "
+                               "vision_amd has no CPU fallback")
+        L = C.CDLL(path)
+        L.vmk_last_error.restype = C.c_char_p
+        L.vmk_last_error.argtypes = [C.c_void_p]
+        L.vmk_abi_version.restype = C.c_uint32
+        L.vmk_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.vmk_destroy.argtypes = [C.c_void_p]
+        L.vmk_upload_scene.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_build_accel.argtypes = [C.c_void_p]
+        L.vmk_set_render_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_set_framebuffer.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_reset_accum.argtypes = [C.c_void_p]
+        L.vmk_render_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]
+        L.vmk_synchronize.argtypes = [C.c_void_p]
+        L.vmk_download_accum.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_tonemap.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vmk_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_reset_counters.argtypes = [C.c_void_p]
+        L.vmk_stream.restype = C.c_void_p
+        L.vmk_stream.argtypes = [C.c_void_p]
+        L.vmk_accel_info_get.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_trace_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.POINTER(C.c_float), C.c_uint32]
+        L.vmk_test_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        if L.vmk_abi_version() != _abi.ABI_VERSION:
+            raise BackendError("libvmk.so ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Backend:
+    """One ctx per GPU (not thread-safe), mirroring the call order of Vision's Pipeline::prepare / render."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.vmk_create(device, C.byref(h))
+        if rc != 0:
+            raise BackendError(self._L.vmk_last_error(None).decode() or f"vmk_create failed ({rc})")
+        self._h = h
+        self.params = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BackendError(f"{self._L.vmk_last_error(self._h).decode()} (status {rc})")
+
+    def upload_scene(self, host_scene):
+        self._check(self._L.vmk_upload_scene(self._h, C.cast(host_scene.tables, C.c_void_p)))
+
+    def build_accel(self):
+        self._check(self._L.vmk_build_accel(self._h))
+        info = _abi.AccelInfo()
+        self._check(self._L.vmk_accel_info_get(self._h, C.byref(info)))
+        return {n: getattr(info, n) for n, _ in info._fields_}
+
+    def set_render_params(self, params):
+        self.params = params
+        self._check(self._L.vmk_set_render_params(self._h, C.byref(params)))
+
+    def set_framebuffer(self, device_ptr):
+        self._check(self._L.vmk_set_framebuffer(self._h, C.c_void_p(device_ptr) if device_ptr else None))
+
+    def reset_accum(self):
+        self._check(self._L.vmk_reset_accum(self._h))
+
+    def render_batch(self, frame_begin, frame_count, tiles=None, timed=False):
+        ms = C.c_float(0.0)
+        self._check(self._L.vmk_render_batch(self._h, frame_begin, frame_count, C.byref(tiles) if tiles else None,
+                                             C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    def synchronize(self):
+        self._check(self._L.vmk_synchronize(self._h))
+
+    def download_accum(self):
+        out = np.zeros((self.params.height, self.params.width, 4), np.float32)
+        self._check(self._L.vmk_download_accum(self._h, _ptr(out)))
+        return out
+
+    def tonemap(self, final_picture=False):
+        out = np.zeros((self.params.height, self.params.width, 4), np.float32)
+        self._check(self._L.vmk_tonemap(self._h, int(final_picture), _ptr(out)))
+        return out
+
+    def counters(self):
+        c = _abi.Counters()
+        self._check(self._L.vmk_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(self._L.vmk_reset_counters(self._h))
+
+    @property
+    def stream(self):
+        return self._L.vmk_stream(self._h)
+
+    def trace(self, org, dirs, tmax, any_hit=False, repeats=1):
+        org = np.ascontiguousarray(org, np.float32)
+        dirs = np.ascontiguousarray(dirs, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = org.shape[0]
+        out = np.zeros((n, 4), np.uint32)
+        ms = C.c_float(0.0)
+        self._check(self._L.vmk_trace_rays(self._h, n, _ptr(org), _ptr(dirs), _ptr(tmax), int(any_hit), _ptr(out),
+                                           C.byref(ms), repeats))
+        return out, ms.value
+
+    def test_eval(self, kind, inp, out_stride):
+        inp = np.ascontiguousarray(inp, np.float32)
+        out = np.zeros((inp.shape[0], out_stride), np.float32)
+        self._check(self._L.vmk_test_eval(self._h, kind, inp.shape[0], _ptr(inp), inp.shape[1], _ptr(out), out_stride))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vmk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,983 @@
+// dpath.h — device functions of the path-tracing hot path, hand-written for gfx950.
+// Each block cites the Vision source (`src/`-relative file:line) whose arithmetic it reproduces.
+#pragma once
+#include "dscene.h"
+
+namespace vmkd {
+
+// =====================================================================================================
+// a1. sampler: TEA-seeded LCG — render_core/sampler/independent.cpp:24-42, math/util.h:13-33
+// =====================================================================================================
+VD uint32_t tea(uint32_t v0, uint32_t v1) {
+    uint32_t s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+struct Sampler {
+    uint32_t state;
+    VD void start(uint32_t px, uint32_t py, uint32_t sample_index, uint32_t dim) { state = tea(tea(px, py), tea(sample_index, dim)); }
+    VD float next_1d() {
+        state = 1664525u * state + 1013904223u;
+        return ((float) (state & 0x00ffffffu) * 1.f) * (1.f / 16777216.f);
+    }
+    VD V2 next_2d() { float x = next_1d(); float y = next_1d(); return {x, y}; }
+};
+
+// =====================================================================================================
+// warps / MIS — math/warp.h
+// =====================================================================================================
+VD V2 square_to_disk(V2 u) { // warp.h:26-31
+    float r = sqrt_(u.x);
+    float theta = _2Pi * u.y;
+    float s, c; sincos_(theta, &s, &c);
+    return {r * c, r * s};
+}
+VD V3 square_to_cosine_hemisphere(V2 u) { // warp.h:38-43
+    V2 d = square_to_disk(u);
+    float z = sqrt_(fmax_(0.f, 1.f - d.x * d.x - d.y * d.y));
+    return {d.x, d.y, z};
+}
+VD float cosine_hemisphere_PDF(float cos_t) { return cos_t * InvPi; }
+VD V2 square_to_triangle(V2 u) { float su0 = sqrt_(u.x); return {1.f - su0, u.y * su0}; } // warp.h:65-69
+VD float sample_linear(float u, float a, float b) { // warp.h:122-128
+    float x = u * (a + b) / (a + sqrt_(lerp_(u, sqr(a), sqr(b))));
+    float ret = fmin_(x, OneMinusEpsilon);
+    return (u == 0.f && a == 0.f) ? 0.f : ret;
+}
+VD float sample_tent(float u, float r) { // warp.h:131-146
+    return u < 0.5f ? -r * sample_linear((0.5f - u) * 2.f, 1.f, 0.f) : r * sample_linear((u - 0.5f) * 2.f, 1.f, 0.f);
+}
+VD float MIS_weight(float f_pdf, float g_pdf) { return (1.f * f_pdf) / (1.f * f_pdf + 1.f * g_pdf); } // warp.h:149-199
+VD float PDF_wi(float pdf_point, V3 normal, V3 wo_un) { // warp.h:89-94
+    float cos_t = abs_(dot(normal, normalize(wo_un)));
+    return pdf_point * length_squared(wo_un) / cos_t;
+}
+VD float remapping(float a, float low, float high) { return (a - low) / (high - low); }
+
+// =====================================================================================================
+// textures / LUTs: manual bilinear / trilinear on plain HBM arrays (no texture objects).
+// tex.sample semantics: normalised coords, texel centres at (i+0.5)/N, repeat wrap (images), clamp (LUTs).
+// =====================================================================================================
+VD V4 fetch_texel(const DScene &S, const vmk_texture &t, int x, int y) {
+    const uint8_t *base = S.tex_data + t.offset;
+    size_t i = (size_t) y * t.width + (size_t) x;
+    if (t.format == VMK_TEX_RGBA32F) {
+        float4 p = *reinterpret_cast<const float4 *>(base + i * 16);
+        return {p.x, p.y, p.z, p.w};
+    }
+    uint32_t p = *reinterpret_cast<const uint32_t *>(base + i * 4);
+    uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu, a = p >> 24;
+    if (t.format == VMK_TEX_RGBA8_SRGB) return {S.srgb_lut[r], S.srgb_lut[g], S.srgb_lut[b], (float) a * (1.f / 255.f)};
+    return {(float) r * (1.f / 255.f), (float) g * (1.f / 255.f), (float) b * (1.f / 255.f), (float) a * (1.f / 255.f)};
+}
+VD int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+VD V4 sample_image(const DScene &S, uint32_t tex_id, V2 uv, DCounters &cnt) {
+    const vmk_texture t = S.textures[tex_id];
+    float x = uv.x * (float) t.width - 0.5f, y = uv.y * (float) t.height - 0.5f;
+    float fx0 = floor_(x), fy0 = floor_(y);
+    float tx = x - fx0, ty = y - fy0;
+    int x0 = wrap_repeat((int) fx0, (int) t.width), y0 = wrap_repeat((int) fy0, (int) t.height);
+    int x1 = wrap_repeat((int) fx0 + 1, (int) t.width), y1 = wrap_repeat((int) fy0 + 1, (int) t.height);
+    V4 c00 = fetch_texel(S, t, x0, y0), c10 = fetch_texel(S, t, x1, y0);
+    V4 c01 = fetch_texel(S, t, x0, y1), c11 = fetch_texel(S, t, x1, y1);
+    cnt.tex++;
+    return lerp4(ty, lerp4(tx, c00, c10), lerp4(tx, c01, c11));
+}
+VD int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+template<int NC>
+VD void sample_lut2d(const float *lut, float u, float v, float *out) {
+    const int N = VMK_LUT_RES;
+    float x = u * (float) N - 0.5f, y = v * (float) N - 0.5f;
+    float fx0 = floor_(x), fy0 = floor_(y);
+    float tx = x - fx0, ty = y - fy0;
+    int x0 = clampi((int) fx0, 0, N - 1), x1 = clampi((int) fx0 + 1, 0, N - 1);
+    int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float c00 = lut[(y0 * N + x0) * NC + c], c10 = lut[(y0 * N + x1) * NC + c];
+        float c01 = lut[(y1 * N + x0) * NC + c], c11 = lut[(y1 * N + x1) * NC + c];
+        out[c] = lerp_(ty, lerp_(tx, c00, c10), lerp_(tx, c01, c11));
+    }
+}
+template<int NC>
+VD void sample_lut3d(const float *lut, V3 uvw, float *out) {
+    const int N = VMK_LUT_RES;
+    float x = uvw.x * (float) N - 0.5f, y = uvw.y * (float) N - 0.5f, z = uvw.z * (float) N - 0.5f;
+    float fx0 = floor_(x), fy0 = floor_(y), fz0 = floor_(z);
+    float tx = x - fx0, ty = y - fy0, tz = z - fz0;
+    int x0 = clampi((int) fx0, 0, N - 1), x1 = clampi((int) fx0 + 1, 0, N - 1);
+    int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
+    int z0 = clampi((int) fz0, 0, N - 1), z1 = clampi((int) fz0 + 1, 0, N - 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float v000 = lut[((z0 * N + y0) * N + x0) * NC + c], v100 = lut[((z0 * N + y0) * N + x1) * NC + c];
+        float v010 = lut[((z0 * N + y1) * N + x0) * NC + c], v110 = lut[((z0 * N + y1) * N + x1) * NC + c];
+        float v001 = lut[((z1 * N + y0) * N + x0) * NC + c], v101 = lut[((z1 * N + y0) * N + x1) * NC + c];
+        float v011 = lut[((z1 * N + y1) * N + x0) * NC + c], v111 = lut[((z1 * N + y1) * N + x1) * NC + c];
+        float a = lerp_(ty, lerp_(tx, v000, v100), lerp_(tx, v010, v110));
+        float b = lerp_(ty, lerp_(tx, v001, v101), lerp_(tx, v011, v111));
+        out[c] = lerp_(tz, a, b);
+    }
+}
+// ShaderNodeSlot::evaluate (shader_node.cpp:242-273): constant or image*scale, swizzled
+VD V3 eval_slot3(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt) {
+    if (sl.tex == VMK_INVALID) return {sl.v[0], sl.v[1], sl.v[2]};
+    V4 t = sample_image(S, sl.tex & 0xffffu, uv, cnt);
+    float c[4] = {t.x * sl.v[0], t.y * sl.v[0], t.z * sl.v[0], t.w * sl.v[0]};
+    uint32_t sw = sl.tex >> 16;
+    auto pick = [&](uint32_t k) { return k == 0 ? c[0] : (k == 1 ? c[1] : (k == 2 ? c[2] : c[3])); };
+    return {pick(sw & 3u), pick((sw >> 2) & 3u), pick((sw >> 4) & 3u)};
+}
+VD float eval_slot1(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt) {
+    if (sl.tex == VMK_INVALID) return sl.v[0];
+    return eval_slot3(S, sl, uv, cnt).x;
+}
+
+// =====================================================================================================
+// a5. Interaction — Geometry::compute_surface_interaction (base/mgr/geometry.cpp:79-166)
+// =====================================================================================================
+struct Interaction {
+    V3 pos, wo, ng;
+    V2 uv;
+    Frame shading;
+    float prim_area;
+    uint32_t prim_id, mat_id, light_id;
+};
+VD V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+VD V2 ld2(const float *p) { return {p[0], p[1]}; }
+VD V3 triangle_lerp(V2 b, V3 a0, V3 a1, V3 a2) { return a0 * (1.f - b.x - b.y) + a1 * b.x + a2 * b.y; }
+VD V2 triangle_lerp2(V2 b, V2 a0, V2 a1, V2 a2) {
+    float w = 1.f - b.x - b.y;
+    return {a0.x * w + a1.x * b.x + a2.x * b.y, a0.y * w + a1.y * b.x + a2.y * b.y};
+}
+// `tri` indexes the Morton-ordered triangle arrays. COMPLETE = is_complete of the reference.
+template<bool COMPLETE>
+VD void compute_surface_interaction(const DScene &S, uint32_t tri, uint32_t inst_id, uint32_t prim_id, V2 bary, Interaction &it) {
+    const vmk_tri_pos *tp = S.tri_pos + tri;
+    const vmk_tri_attr *ta = S.tri_attr + tri;
+    const vmk_instance *inst = S.instances + inst_id;
+    it.prim_id = prim_id; it.light_id = inst->light_id; it.mat_id = inst->mat_id;
+    V3 p0 = ld3(tp->p0), p1 = ld3(tp->p1), p2 = ld3(tp->p2);
+    it.pos = triangle_lerp(bary, p0, p1, p2);
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    V3 ng_un = cross(dp02, dp12);
+    it.prim_area = 0.5f * length(ng_un);
+    V2 t0 = ld2(ta->uv0), t1 = ld2(ta->uv1), t2 = ld2(ta->uv2);
+    it.uv = triangle_lerp2(bary, t0, t1, t2);
+    V3 ngn = normalize(ng_un);
+    it.ng = ngn;
+    if constexpr (COMPLETE) {
+        V2 duv02 = t0 - t2, duv12 = t1 - t2;
+        float det = duv02.x * duv12.y - duv02.y * duv12.x;
+        bool degenerate_uv = abs_(det) < 1e-8f;
+        V3 dp_du, dp_dv;
+        if (!degenerate_uv) {
+            float inv_det = 1.f / det;
+            dp_du = normalize((dp02 * duv12.y - dp12 * duv02.y) * inv_det);
+            dp_dv = normalize((dp02 * (-duv12.x) + dp12 * duv02.x) * inv_det);
+        } else {
+            dp_du = normalize(p1 - p0);
+            dp_dv = normalize(p2 - p0);
+        }
+        it.shading = {dp_du, dp_dv, ngn};
+        V3 normal = triangle_lerp(bary, ld3(ta->n0), ld3(ta->n1), ld3(ta->n2));
+        if (!is_zero(normal)) { // PartialDerivative::update (interaction.h:101-105)
+            V3 ns = normalize(mul3x3(inst->n2w, normal));
+            it.shading.z = ns;
+            it.shading.x = normalize(cross(ns, it.shading.y)) * length(it.shading.x);
+            it.shading.y = normalize(cross(ns, it.shading.x)) * length(it.shading.y);
+        }
+    } else {
+        it.shading = {dp02, dp12, ngn};
+    }
+}
+
+struct Ray { V3 o, d; float t_max; };
+// a6. spawn rays — interaction.h:279-309
+VD Ray spawn_ray(V3 pos, V3 normal, V3 dir) {
+    normal = normal * (dot(normal, dir) > 0.f ? 1.f : -1.f);
+    return {offset_ray_origin(pos, normal), dir, RayTMax};
+}
+VD Ray spawn_ray_to(V3 p_start, V3 n_start, V3 p_target) {
+    V3 dir = p_target - p_start;
+    n_start = n_start * (dot(n_start, dir) > 0.f ? 1.f : -1.f);
+    return {offset_ray_origin(p_start, n_start), dir, 1.f - ShadowEpsilon};
+}
+VD V3 robust_pos(V3 pos, V3 ng, V3 dir, float factor) { // interaction.h:321-324
+    float f = dot(ng, dir) > 0.f ? 1.f : -1.f;
+    return offset_ray_origin(pos, (ng * f) * factor);
+}
+
+// =====================================================================================================
+// a13. GGX microfacet — base/scattering/microfacet.{h,cpp}
+// =====================================================================================================
+VD V2 calculate_alpha(float alpha, float anisotropic) { // microfacet.h:43-58
+    float ax = anisotropic < 0.f ? alpha / (1.f + anisotropic) : alpha * (1.f - anisotropic);
+    float ay = anisotropic < 0.f ? alpha * (1.f + anisotropic) : alpha / (1.f - anisotropic);
+    if (abs_(anisotropic) <= 1e-4f) return {alpha, alpha};
+    return {ax, ay};
+}
+VD float bsdf_D(V3 wh, float ax, float ay) { // microfacet.cpp:18-22
+    V3 H = {wh.x / ax, wh.y / ay, wh.z / 1.f};
+    float alpha2 = ax * ay;
+    return InvPi / (alpha2 * sqr(length_squared(H)));
+}
+VD float bsdf_lambda(V3 w, float ax, float ay) { // microfacet.cpp:43-47
+    float sqr_alpha_tan_n = (sqr(ax * w.x) + sqr(ay * w.y)) / sqr(w.z);
+    float ret = 0.5f * (sqrt_(1.0f + sqr_alpha_tan_n) - 1.0f);
+    return w.z == 0.f ? 0.f : ret;
+}
+VD float bsdf_G1(V3 w, float ax, float ay) { return 1.f / (1.f + bsdf_lambda(w, ax, ay)); }
+VD float bsdf_G(V3 wo, V3 wi, float ax, float ay) { return 1.f / (1.f + bsdf_lambda(wo, ax, ay) + bsdf_lambda(wi, ax, ay)); }
+VD V3 sample_GGX_VNDF(V3 Ve, V2 u, float ax, float ay) { // microfacet.cpp:73-95
+    V3 Vh = normalize(mk3(ax * Ve.x, ay * Ve.y, Ve.z));
+    float lenSq = Vh.x * Vh.x + Vh.y * Vh.y;
+    V3 T1 = lenSq > 1e-7f ? mk3(-Vh.y, Vh.x, 0.0f) / sqrt_(lenSq) : mk3(1, 0, 0);
+    V3 T2 = lenSq > 1e-7f ? cross(Vh, T1) : mk3(0.0f, 1.0f, 0.0f);
+    V2 t = square_to_disk(u);
+    t.y = lerp_(0.5f * (1.0f + Vh.z), safe_sqrt(1.0f - sqr(t.x)), t.y);
+    V3 Nh = T1 * t.x + T2 * t.y + Vh * safe_sqrt(1.0f - (t.x * t.x + t.y * t.y));
+    return normalize(mk3(ax * Nh.x, ay * Nh.y, fmax_(0.0f, Nh.z)));
+}
+VD V3 sample_wh(V3 wo, V2 u, float ax, float ay) { // microfacet.cpp:102-112
+    bool flip = wo.z < 0.f;
+    V3 wh = sample_GGX_VNDF(flip ? -wo : wo, u, ax, ay);
+    return flip ? -wh : wh;
+}
+VD float PDF_wh(V3 wo, V3 wh, float ax, float ay) { // microfacet.cpp:152-159 (sample_visible)
+    return bsdf_D(wh, ax, ay) * bsdf_G1(wo, ax, ay) * abs_dot(wo, wh) / abs_cos_theta(wo);
+}
+VD float PDF_wi_reflection(V3 wo, V3 wh, float ax, float ay) { return PDF_wh(wo, wh, ax, ay) / (4.f * abs_dot(wo, wh)); }
+VD float PDF_wi_transmission(V3 wo, V3 wh, V3 wi, float eta, float ax, float ay) { // microfacet.h:159-165
+    float denom = sqr(dot(wi, wh) * eta + dot(wo, wh));
+    float dwh_dwi = abs_dot(wi, wh) / denom;
+    return PDF_wh(wo, wh, ax, ay) * dwh_dwi;
+}
+VD float BRDF_div_fr(V3 wo, V3 wh, V3 wi, float ax, float ay) { // microfacet.h:168-175
+    return bsdf_D(wh, ax, ay) * bsdf_G(wo, wi, ax, ay) / abs_(4.f * cos_theta(wo) * cos_theta(wi));
+}
+VD float BTDF_div_ft(V3 wo, V3 wh, V3 wi, float eta, float ax, float ay, bool radiance) { // microfacet.cpp:166-179
+    float cos_i = cos_theta(wi), cos_o = cos_theta(wo);
+    float numerator = bsdf_D(wh, ax, ay) * bsdf_G(wo, wi, ax, ay) * abs_(dot(wi, wh) * dot(wo, wh));
+    float denom = sqr(dot(wi, wh) * eta + dot(wo, wh)) * abs_(cos_i * cos_o);
+    float ft = numerator / denom;
+    float factor = radiance ? rcp(sqr(eta)) : 1.f;
+    ft = denom == 0.f ? 0.f : ft;
+    return ft * factor;
+}
+
+// =====================================================================================================
+// a14. Fresnel — math/optics.h, math/complex.h, base/scattering/fresnel.h, metal.cpp:14-26
+// =====================================================================================================
+VD bool refract(V3 wi, V3 n, float eta, V3 *wt) { // optics.h:28-39
+    float cos_i = dot(n, wi);
+    float sin_i_2 = fmax_(0.f, 1.f - sqr(cos_i));
+    float sin_t_2 = sin_i_2 / sqr(eta);
+    bool valid = sin_t_2 < 1.f;
+    float cos_t = safe_sqrt(1.f - sin_t_2);
+    *wt = -wi / eta + n * (cos_i / eta - cos_t);
+    return valid;
+}
+VD float schlick_weight(float cos_t) { return pow5(clamp_(1.f - cos_t, 0.f, 1.f)); }
+VD float schlick_F0_from_ior(float ior) { return sqr((ior - 1.0f) / (ior + 1.0f)); }
+VD float schlick_ior_from_F0(float f0) { float s = sqrt_(clamp_(f0, 0.0f, 0.99f)); return (1.0f + s) / (1.0f - s); }
+VD float fresnel_dielectric(float abs_cos_i, float eta) { // optics.h:71-78
+    float sin_i_2 = 1.f - sqr(abs_cos_i);
+    float sin_t_2 = sin_i_2 / sqr(eta);
+    float cos_t = safe_sqrt(1.f - sin_t_2);
+    float r_parl = (eta * abs_cos_i - cos_t) / (eta * abs_cos_i + cos_t);
+    float r_perp = (abs_cos_i - eta * cos_t) / (abs_cos_i + eta * cos_t);
+    return sin_t_2 >= 1.f ? 1.f : (sqr(r_parl) + sqr(r_perp)) * 0.5f;
+}
+struct Cpx { float re, im; };
+VD Cpx cadd(Cpx a, Cpx b) { return {a.re + b.re, a.im + b.im}; }
+VD Cpx csub(Cpx a, Cpx b) { return {a.re - b.re, a.im - b.im}; }
+VD Cpx cmul(Cpx a, Cpx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+VD Cpx cdiv(Cpx a, Cpx z) { float sc = 1.f / (z.re * z.re + z.im * z.im); return {sc * (a.re * z.re + a.im * z.im), sc * (a.im * z.re - a.re * z.im)}; }
+VD float cnorm_sqr(Cpx z) { return z.re * z.re + z.im * z.im; }
+VD Cpx csqrt(Cpx z) { // complex.h:61-69
+    float n = sqrt_(cnorm_sqr(z));
+    float t1 = sqrt_(0.5f * (n + abs_(z.re)));
+    float t2 = 0.5f * z.im / t1;
+    Cpx r;
+    r.re = n == 0.f ? 0.f : (z.re >= 0.f ? t1 : abs_(t2));
+    r.im = n == 0.f ? 0.f : (z.re >= 0.f ? t2 : u2f((f2u(t1) & 0x7fffffffu) | (f2u(z.im) & 0x80000000u)));
+    return r;
+}
+VD float fresnel_complex(float cos_i, float eta_re, float k) { // optics.h:93-102
+    Cpx eta = {eta_re, k};
+    float sin_i_2 = 1.f - sqr(cos_i);
+    Cpx sin_t_2 = cdiv(Cpx{sin_i_2, 0.f}, cmul(eta, eta));
+    Cpx cos_t = csqrt(csub(Cpx{1.f, 0.f}, sin_t_2));
+    Cpx ci = {cos_i, 0.f};
+    Cpx r_parl = cdiv(csub(cmul(eta, ci), cos_t), cadd(cmul(eta, ci), cos_t));
+    Cpx r_perp = cdiv(csub(ci, cmul(eta, cos_t)), cadd(ci, cmul(eta, cos_t)));
+    return (cnorm_sqr(r_parl) + cnorm_sqr(r_perp)) * .5f;
+}
+enum : int { FR_CONSTANT = 0, FR_CONDUCTOR, FR_DIELECTRIC, FR_SCHLICK, FR_F82 };
+struct Fresnel {
+    int kind;
+    V3 a, b; // conductor eta,k | schlick F0 | F82 F0,B
+    float eta;
+    VD V3 evaluate(float cos_t) const {
+        if (kind == FR_CONDUCTOR) return {fresnel_complex(cos_t, a.x, b.x), fresnel_complex(cos_t, a.y, b.y), fresnel_complex(cos_t, a.z, b.z)};
+        if (kind == FR_DIELECTRIC) { float f = fresnel_dielectric(cos_t, eta); return {f, f, f}; }
+        if (kind == FR_SCHLICK) { // fresnel.h:60-67
+            float F_real = fresnel_dielectric(cos_t, eta);
+            float F0_real = schlick_F0_from_ior(eta);
+            float t = clamp_(inverse_lerp(F_real, F0_real, 1.f), 0.f, 1.f);
+            return lerp3(t, a, mk3(1.f));
+        }
+        if (kind == FR_F82) { // fresnel.h:123-129
+            float mu = saturate_(1.f - cos_t);
+            float mu5 = pow5(mu);
+            V3 f_schlick = lerp3(mu5, a, mk3(1.f));
+            return saturate3(f_schlick - b * cos_t * mu5 * mu);
+        }
+        return {1.f, 1.f, 1.f};
+    }
+};
+
+// =====================================================================================================
+// a11-a18. lobes + materials — base/scattering/{bxdf,lobe,material}.cpp, render_core/material/*.cpp
+// The reference builds a polymorphic Lobe tree per hit; here every material expands to a short, fixed list of
+// flat lobe records sharing the interaction's shading frame, evaluated by a switch on the lobe kind.
+// =====================================================================================================
+namespace flag {
+constexpr uint32_t Unset = 1, Reflection = 2, Transmission = 4, Diffuse = 8, Glossy = 16;
+constexpr uint32_t DiffRefl = Diffuse | Reflection, GlossyRefl = Glossy | Reflection, GlossyTrans = Glossy | Transmission;
+}
+struct ScatterEval { V3 f; float pdf; uint32_t flags; };
+struct BSDFSample { ScatterEval eval; V3 wi; float eta; };
+enum : int { LB_LAMBERT = 0, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_DIELECTRIC, LB_SHEEN };
+struct Lobe {
+    int kind;
+    V3 kr, rs;
+    float A, B, ax, ay;
+    Fresnel fr;
+    bool compensate;
+    float weight, sample_weight;
+};
+
+VD float dielectric_refl_prob(const Lobe &l, V3 F) { // lobe.cpp:315-319
+    V3 T = 1.f - F;
+    V3 total = T * l.kr + F;
+    return average(F) / average(total);
+}
+VD float dielectric_lut_x(const DScene &S, const Lobe &l, V3 wo, float eta) { // lobe.cpp:263-285
+    const float *lut = eta > 1.f ? S.lut_dielectric : S.lut_dielectric_inv;
+    float x = sqrt_(sqrt_(l.ax * l.ay));
+    float y = abs_cos_theta(wo);
+    float z = eta > 1.f ? inverse_lerp(eta, 1.003f, 5.f) : inverse_lerp(rcp(eta), 1.003f, 5.f);
+    float out[2]; sample_lut3d<2>(lut, mk3(x, y, z), out);
+    return out[0];
+}
+VD V3 blend_f_specular(const Lobe &l, V3 wo, V3 wi, V3 wh) { // FresnelBlend::f_specular substrate.cpp:31-37
+    V3 specular = lerp3(schlick_weight(dot(wi, wh)), l.rs, mk3(1.f)) *
+                  (bsdf_D(wh, l.ax, l.ay) / (4.f * abs_dot(wi, wh) * fmax_(abs_cos_theta(wi), abs_cos_theta(wo))));
+    return specular * (is_zero(wh) ? 0.f : 1.f);
+}
+
+// Lobe::evaluate_local_impl of every lobe class (local frame, before the |cos_i| factor)
+VD ScatterEval eval_local(const DScene &S, const Lobe &l, V3 wo, V3 wi, float *eta_out) {
+    ScatterEval se; se.f = mk3(0.f); se.pdf = 0.f; se.flags = flag::Unset;
+    switch (l.kind) {
+        case LB_LAMBERT: case LB_OREN_NAYAR: { // bxdf.cpp:34-46, bxdf.h:92-95, bxdf.cpp:103-121
+            bool sh = same_hemisphere(wo, wi);
+            V3 f;
+            if (l.kind == LB_LAMBERT) f = l.kr * InvPi;
+            else {
+                float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
+                float d_cos = cos_phi(wi) * cos_phi(wo) + sin_phi(wi) * sin_phi(wo);
+                float max_cos = fmax_(0.f, d_cos);
+                bool cond = abs_cos_theta(wi) > abs_cos_theta(wo);
+                float sin_alpha = cond ? sin_o : sin_i;
+                float tan_beta = cond ? sin_i / abs_cos_theta(wi) : sin_o / abs_cos_theta(wo);
+                f = l.kr * InvPi * (l.A + l.B * max_cos * sin_alpha * tan_beta);
+            }
+            se.f = sh ? f : mk3(0.f);
+            se.pdf = sh ? cosine_hemisphere_PDF(abs_cos_theta(wi)) : 0.f;
+            se.flags = flag::DiffRefl;
+            break;
+        }
+        case LB_MICROFACET: { // lobe.cpp:213-218, bxdf.cpp:65-78, lobe.cpp:716-729
+            bool sh = same_hemisphere(wo, wi);
+            V3 wh = normalize(wo + wi);
+            V3 whf = face_forward(wh, mk3(0, 0, 1));
+            V3 F = l.fr.evaluate(abs_dot(wo, whf));
+            V3 f = (F * BRDF_div_fr(wo, whf, wi, l.ax, l.ay)) * l.kr;
+            float pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay);
+            se.f = sh ? f : mk3(0.f);
+            se.pdf = sh ? pdf : 0.f;
+            se.flags = flag::GlossyRefl;
+            if (l.compensate) {
+                float alpha = sqrt_(l.ax * l.ay);
+                float v; sample_lut2d<1>(S.lut_pure_reflection, alpha, cos_theta(wo), &v);
+                se.f *= 1.f / v;
+            }
+            break;
+        }
+        case LB_FRESNEL_BLEND: { // substrate.cpp:12-70
+            bool sh = same_hemisphere(wo, wi);
+            V3 wh = normalize(wi + wo);
+            V3 specular = blend_f_specular(l, wo, wi, wh);
+            V3 diffuse = (28.f / (23.f * Pi)) * l.kr * (mk3(1.f) - l.rs) *
+                         (1.f - pow5(1.f - .5f * abs_cos_theta(wi))) * (1.f - pow5(1.f - .5f * abs_cos_theta(wo)));
+            V3 f = specular + diffuse;
+            float fr = l.fr.evaluate(abs_cos_theta(wo)).x;
+            float pdf = lerp_(fr, cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
+            se.f = sh ? f : mk3(0.f);
+            se.pdf = sh ? pdf : 0.f;
+            se.flags = flag::Reflection;
+            break;
+        }
+        case LB_DIELECTRIC: { // lobe.cpp:321-412
+            bool refl = same_hemisphere(wo, wi);
+            float eta = l.fr.eta;
+            float eta_p = refl ? 1.f : eta;
+            if (eta_out) *eta_out = eta_p;
+            V3 wh = normalize(wo + wi * eta_p);
+            wh = face_forward(wh, wo);
+            V3 F = l.fr.evaluate(abs_dot(wh, wo));
+            float lutx = dielectric_lut_x(S, l, wo, eta);
+            if (refl) {
+                se.f = F * BRDF_div_fr(wo, wh, wi, l.ax, l.ay);
+                se.pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay) * dielectric_refl_prob(l, F);
+                se.flags = flag::GlossyRefl;
+                se.f *= rcp(lutx);
+            } else {
+                V3 new_wh = face_forward(wh, wo);
+                V3 wh2 = normalize(wo + wi * eta);
+                V3 tr = (1.f - F) * BTDF_div_ft(wo, wh2, wi, eta, l.ax, l.ay, true);
+                se.f = tr * l.kr;
+                se.pdf = PDF_wi_transmission(wo, new_wh, wi, eta, l.ax, l.ay) * (1.f - dielectric_refl_prob(l, F));
+                se.flags = flag::GlossyTrans;
+                se.f *= rcp(lutx);
+            }
+            break;
+        }
+        default: { // LB_SHEEN principled_bsdf.cpp:58-72,110-117
+            float cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+            V3 w = mk3(l.A * wi.x + l.B * wi.z, l.A * wi.y, wi.z);
+            float len = length(w);
+            w = w / len;
+            float jacobian = sqr(l.A) / (len * len * len);
+            float ltc = cosine_hemisphere_PDF(cos_theta(w)) * jacobian;
+            se.f = l.kr * ltc / cos_i;
+            se.pdf = ltc;
+            if (cos_i < 0.f || cos_o < 0.f) se.f = mk3(0.f);
+            break;
+        }
+    }
+    return se;
+}
+
+// sample_wi_local_impl of every lobe class
+VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
+    V3 wi;
+    *valid = true;
+    switch (l.kind) {
+        case LB_LAMBERT: case LB_OREN_NAYAR: { // bxdf.cpp:48-52
+            wi = square_to_cosine_hemisphere(sampler.next_2d());
+            wi.z = wo.z < 0.f ? -wi.z : wi.z;
+            break;
+        }
+        case LB_MICROFACET: { // bxdf.cpp:80-84
+            V3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
+            wi = reflect(wo, wh);
+            *valid = same_hemisphere(wo, wi);
+            break;
+        }
+        case LB_FRESNEL_BLEND: { // substrate.cpp:52-69
+            V2 u = sampler.next_2d();
+            float fr = l.fr.evaluate(abs_cos_theta(wo)).x;
+            if (u.x < fr) {
+                u.x = remapping(u.x, 0.f, fr);
+                V3 wh = sample_wh(wo, u, l.ax, l.ay);
+                wi = reflect(wo, wh);
+            } else {
+                u.x = remapping(u.x, fr, 1.f);
+                wi = square_to_cosine_hemisphere(u);
+                wi.z = wo.z < 0.f ? -wi.z : wi.z;
+            }
+            break;
+        }
+        case LB_DIELECTRIC: { // lobe.cpp:431-449
+            V3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
+            float d = dot(wo, wh);
+            V3 F = l.fr.evaluate(abs_(d));
+            float uc = sampler.next_1d();
+            if (uc < dielectric_refl_prob(l, F)) {
+                wi = reflect(wo, wh);
+                *valid = same_hemisphere(wo, wi);
+            } else {
+                bool v = refract(wo, wh, l.fr.eta, &wi);
+                *valid = v && !same_hemisphere(wo, wi);
+            }
+            break;
+        }
+        default: { // LB_SHEEN principled_bsdf.cpp:100-108
+            V3 w = square_to_cosine_hemisphere(sampler.next_2d());
+            w = mk3(w.x / l.A - w.z * l.B / l.A, w.y / l.A, w.z);
+            wi = normalize(w);
+            break;
+        }
+    }
+    return wi;
+}
+
+VD void microfacet_alpha(const DScene &S, const vmk_material *m, int slot_r, int slot_a, V2 uv, float rmin, float *ax, float *ay, DCounters &cnt) {
+    float roughness = clamp_(eval_slot1(S, m->slot[slot_r], uv, cnt), rmin, 1.f);
+    float anisotropic = clamp_(eval_slot1(S, m->slot[slot_a], uv, cnt), -0.9f, 0.9f);
+    roughness = (m->flags & VMK_MATF_REMAP_ROUGHNESS) ? sqr(roughness) : roughness;
+    V2 a = calculate_alpha(roughness, anisotropic);
+    *ax = a.x; *ay = a.y;
+}
+VD void lobe_defaults(Lobe &l) {
+    l.kind = LB_LAMBERT; l.kr = mk3(1.f); l.rs = mk3(0.f); l.A = 0.f; l.B = 0.f; l.ax = 0.f; l.ay = 0.f;
+    l.fr.kind = FR_CONSTANT; l.fr.a = mk3(1.f); l.fr.b = mk3(0.f); l.fr.eta = 1.f;
+    l.compensate = false; l.weight = 1.f; l.sample_weight = 1.f;
+}
+// create_lobe_set of the single-lobe material plugins
+VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interaction &it, Lobe &l, DCounters &cnt) {
+    lobe_defaults(l);
+    switch (m->type) {
+        case VMK_MAT_DIFFUSE: { // diffuse.cpp:21-30, bxdf.cpp:94-101
+            l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            if (m->flags & VMK_MATF_HAS_SIGMA) {
+                float sigma = eval_slot1(S, m->slot[1], it.uv, cnt);
+                sigma = sigma * PiOver2;
+                float sigma2 = sqr(sigma * sigma);
+                l.A = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+                l.B = 0.45f * sigma2 / (sigma2 + 0.09f);
+                l.kind = LB_OREN_NAYAR;
+            }
+            break;
+        }
+        case VMK_MAT_MIRROR: { // mirror.cpp:60-74
+            l.kind = LB_MICROFACET; l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            microfacet_alpha(S, m, 1, 2, it.uv, 0.0001f, &l.ax, &l.ay, cnt);
+            l.compensate = true;
+            break;
+        }
+        case VMK_MAT_METAL: { // metal.cpp:137-156
+            l.kind = LB_MICROFACET;
+            microfacet_alpha(S, m, 2, 3, it.uv, 0.0001f, &l.ax, &l.ay, cnt);
+            l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot3(S, m->slot[0], it.uv, cnt); l.fr.b = eval_slot3(S, m->slot[1], it.uv, cnt);
+            l.compensate = true;
+            break;
+        }
+        case VMK_MAT_GLASS: { // glass.cpp:240-257, interaction.cpp:80-83
+            l.kind = LB_DIELECTRIC; l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            float ior = eval_slot1(S, m->slot[1], it.uv, cnt);
+            float cos_t = dot(it.wo, it.ng);
+            ior = cos_t > 0.f ? ior : rcp(ior);
+            microfacet_alpha(S, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay, cnt);
+            l.fr.kind = FR_DIELECTRIC; l.fr.eta = ior;
+            break;
+        }
+        default: { // VMK_MAT_SUBSTRATE substrate.cpp:126-149
+            l.kind = LB_FRESNEL_BLEND;
+            l.kr = eval_slot3(S, m->slot[0], it.uv, cnt); l.rs = eval_slot3(S, m->slot[1], it.uv, cnt);
+            float ax, ay; microfacet_alpha(S, m, 2, 3, it.uv, 0.0001f, &ax, &ay, cnt);
+            if (m->flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
+            l.ax = clamp_(ax, 0.0001f, 1.f); l.ay = clamp_(ay, 0.0001f, 1.f);
+            l.fr.kind = FR_DIELECTRIC; l.fr.eta = 1.5f;
+            break;
+        }
+    }
+}
+
+VD V3 layering_weight(V3 layer_albedo, V3 weight) { // principled_bsdf.cpp:209-214
+    V3 tmp = {weight.x == 0.f ? 0.f : layer_albedo.x / weight.x, weight.y == 0.f ? 0.f : layer_albedo.y / weight.y,
+              weight.z == 0.f ? 0.f : layer_albedo.z / weight.z};
+    return weight * saturate_(1.f - max_comp(tmp));
+}
+// Per-hit material context: what create_lobe_set computes once.  Principled keeps only the per-lobe colours
+// and sampling weights (PrincipledBSDF::create_lobe_set principled_bsdf.cpp:352-461); lobes are re-expanded
+// on demand by mat_lobe().
+struct MatCtx {
+    const vmk_material *m;
+    int n;        // lobes
+    bool is_set;  // LobeSet semantics (weights, valid_world_factor, 3 burnt draws)
+    Lobe single;  // simple materials: the lobe itself
+    float mixw[2];
+    // principled
+    int first;    // 0 with sheen, 1 without
+    V3 color, spec_tint, kr_sheen, kr_coat, kr_metal, kr_spec, kr_diff;
+    float sheen_a, sheen_b, ax, ay, cc_alpha, cc_ior, ior, eta, w_trans;
+    V3 f82_b, f0_spec, f0_trans;
+    float sw[6];
+};
+VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &it, MatCtx &mc, DCounters &cnt) {
+    mc.m = m;
+    if (m->type == VMK_MAT_MIX) { // mix.cpp:66-71 + LobeSet::create_mix (lobe.cpp:495-508)
+        float frac = eval_slot1(S, m->slot[0], it.uv, cnt);
+        mc.mixw[0] = 1.f - frac; mc.mixw[1] = frac;
+        mc.n = 2; mc.is_set = true;
+        return;
+    }
+    if (m->type != VMK_MAT_PRINCIPLED) {
+        mc.n = 1; mc.is_set = false;
+        build_simple_lobe(S, m, it, mc.single, cnt);
+        return;
+    }
+    mc.is_set = true;
+    V2 uv = it.uv;
+    mc.color = eval_slot3(S, m->slot[VMK_P_COLOR], uv, cnt);
+    mc.ior = eval_slot1(S, m->slot[VMK_P_IOR], uv, cnt);
+    float roughness = clamp_(eval_slot1(S, m->slot[VMK_P_ROUGHNESS], uv, cnt), 0.0001f, 1.f);
+    float anisotropic = eval_slot1(S, m->slot[VMK_P_ANISOTROPIC], uv, cnt);
+    mc.spec_tint = eval_slot3(S, m->slot[VMK_P_SPEC_TINT], uv, cnt);
+    float aspect = sqrt_(1.f - anisotropic * 0.9f);
+    mc.ax = fmax_(0.001f, sqr(roughness) / aspect); mc.ay = fmax_(0.001f, sqr(roughness) * aspect);
+    V3 weight = mk3(1.f);
+    float cos_t = dot(it.wo, it.ng);
+    float front_factor = cos_t > 0.f ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mc.sw[i] = 0.f;
+    mc.first = 1;
+    if (S.lut_sheen_approx) { // sheen (SheenLTC ctor principled_bsdf.cpp:37-45)
+        mc.first = 0;
+        V3 sheen_tint = eval_slot3(S, m->slot[VMK_P_SHEEN_TINT], uv, cnt);
+        float sheen_weight = eval_slot1(S, m->slot[VMK_P_SHEEN_WEIGHT], uv, cnt) * front_factor;
+        float sheen_roughness = eval_slot1(S, m->slot[VMK_P_SHEEN_ROUGHNESS], uv, cnt);
+        float c[4]; sample_lut2d<4>(S.lut_sheen_approx, cos_t, sheen_roughness, c);
+        mc.sheen_a = c[0]; mc.sheen_b = c[1];
+        mc.kr_sheen = (sheen_tint * sheen_weight * weight) * c[2];
+        mc.sw[0] = average(mc.kr_sheen);
+        weight = layering_weight(mc.kr_sheen, weight);
+    }
+    { // coat
+        float cc_weight = eval_slot1(S, m->slot[VMK_P_COAT_WEIGHT], uv, cnt) * front_factor;
+        float cc_roughness = clamp_(eval_slot1(S, m->slot[VMK_P_COAT_ROUGHNESS], uv, cnt), 0.0001f, 1.f);
+        cc_roughness = sqr(cc_roughness);
+        mc.cc_alpha = cc_roughness;
+        mc.cc_ior = eval_slot1(S, m->slot[VMK_P_COAT_IOR], uv, cnt);
+        V3 cc_tint = eval_slot3(S, m->slot[VMK_P_COAT_TINT], uv, cnt);
+        mc.kr_coat = (weight * cc_weight) * cc_tint;
+        float x = sqrt_(sqrt_(cc_roughness * cc_roughness));
+        float z = inverse_lerp(mc.cc_ior, 1.003f, 4.f);
+        float sv; sample_lut3d<1>(S.lut_coat, mk3(x, cos_t, z), &sv);
+        V3 albedo = mc.kr_coat * sv;
+        mc.sw[1] = average(albedo);
+        weight = layering_weight(albedo, weight);
+    }
+    { // metallic (FresnelF82Tint::init_from_F82 fresnel.h:115-121)
+        float metallic = eval_slot1(S, m->slot[VMK_P_METALLIC], uv, cnt) * front_factor;
+        const float f = 6.f / 7.f;
+        const float f5 = pow5(f);
+        V3 f_schlick = lerp3(f5, mc.color, mk3(1.f));
+        mc.f82_b = f_schlick * (7.f / (f5 * f)) * (mk3(1.f) - mc.spec_tint);
+        mc.kr_metal = weight * metallic;
+        mc.sw[2] = metallic * average(weight);
+        weight *= (1.0f - metallic);
+    }
+    { // transmission
+        float trans_weight = eval_slot1(S, m->slot[VMK_P_TRANS_WEIGHT], uv, cnt);
+        mc.eta = cos_t > 0.f ? mc.ior : rcp(mc.ior);
+        V3 t_weight = weight * trans_weight;
+        mc.f0_trans = mc.spec_tint * schlick_F0_from_ior(mc.eta);
+        mc.w_trans = average(t_weight);
+        mc.sw[3] = mc.w_trans;
+        weight *= (1.0f - trans_weight);
+    }
+    { // specular
+        float f0 = schlick_F0_from_ior(mc.ior);
+        mc.f0_spec = mc.spec_tint * f0;
+        mc.kr_spec = weight;
+        float x = sqrt_(sqrt_(mc.ax * mc.ay));
+        float z = sqrt_(abs_((mc.ior - 1.0f) / (mc.ior + 1.0f)));
+        float sv; sample_lut3d<1>(S.lut_specular, mk3(x, cos_t, z), &sv);
+        V3 albedo = lerp3(sv, mc.f0_spec, mk3(1.f)) * mc.kr_spec;
+        mc.sw[4] = average(albedo);
+        weight = layering_weight(albedo, weight);
+    }
+    { // diffuse
+        mc.kr_diff = mc.color * weight * front_factor;
+        mc.sw[5] = average(mc.kr_diff);
+    }
+    float weight_sum = 0.f; // LobeSet::normalize_sampled_weight lobe.cpp:524-532
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i >= mc.first) weight_sum += mc.sw[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i >= mc.first) mc.sw[i] = mc.sw[i] / weight_sum;
+    mc.n = 6 - mc.first;
+}
+// expand lobe `i` (0-based within the material's lobe list)
+VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i, Lobe &l, DCounters &cnt) {
+    const vmk_material *m = mc.m;
+    if (m->type == VMK_MAT_MIX) {
+        build_simple_lobe(S, S.materials + (i == 0 ? m->child0 : m->child1), it, l, cnt);
+        l.weight = mc.mixw[i]; l.sample_weight = mc.mixw[i];
+        return;
+    }
+    if (m->type != VMK_MAT_PRINCIPLED) { l = mc.single; return; }
+    lobe_defaults(l);
+    int k = i + mc.first;
+    l.sample_weight = k == 0 ? mc.sw[0] : k == 1 ? mc.sw[1] : k == 2 ? mc.sw[2] : k == 3 ? mc.sw[3] : k == 4 ? mc.sw[4] : mc.sw[5];
+    switch (k) {
+        case 0: l.kind = LB_SHEEN; l.A = mc.sheen_a; l.B = mc.sheen_b; l.kr = mc.kr_sheen; break;
+        case 1: l.kind = LB_MICROFACET; l.ax = l.ay = mc.cc_alpha; l.fr.kind = FR_DIELECTRIC; l.fr.eta = mc.cc_ior; l.kr = mc.kr_coat; break;
+        case 2: l.kind = LB_MICROFACET; l.ax = mc.ax; l.ay = mc.ay; l.fr.kind = FR_F82; l.fr.a = mc.color; l.fr.b = mc.f82_b; l.kr = mc.kr_metal; l.compensate = true; break;
+        case 3: l.kind = LB_DIELECTRIC; l.ax = mc.ax; l.ay = mc.ay; l.fr.kind = FR_SCHLICK; l.fr.a = mc.f0_trans; l.fr.eta = mc.eta; l.kr = mc.color; l.weight = mc.w_trans; break;
+        case 4: l.kind = LB_MICROFACET; l.ax = mc.ax; l.ay = mc.ay; l.fr.kind = FR_SCHLICK; l.fr.a = mc.f0_spec; l.fr.eta = mc.ior; l.kr = mc.kr_spec; break;
+        default: l.kind = LB_LAMBERT; l.kr = mc.kr_diff; break;
+    }
+}
+// Lobe::evaluate / LobeSet::evaluate_impl (lobe.cpp:53-75,673-688) in world space; all lobes share it.shading
+VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Interaction &it, V3 world_wo, V3 world_wi, float *eta, DCounters &cnt) {
+    V3 wo = it.shading.to_local(world_wo), wi = it.shading.to_local(world_wi);
+    if (!mc.is_set) {
+        ScatterEval se = eval_local(S, mc.single, wo, wi, eta);
+        se.f *= abs_cos_theta(wi);
+        return se;
+    }
+    ScatterEval ret; ret.f = mk3(0.f); ret.pdf = 0.f; ret.flags = flag::Unset;
+    bool sh_world = same_hemisphere(world_wo, world_wi, it.shading.z);
+    for (int i = 0; i < mc.n; ++i) {
+        Lobe l; mat_lobe(S, mc, it, i, l, cnt);
+        ScatterEval se = eval_local(S, l, wo, wi, eta);
+        se.f *= abs_cos_theta(wi);
+        float factor = l.kind == LB_DIELECTRIC ? 1.f : (sh_world ? 1.f : 0.f); // valid_world_factor lobe.cpp:35-38,373-375
+        se.f *= l.weight * factor;
+        se.pdf *= l.sample_weight * factor;
+        ret.f += se.f;
+        ret.pdf += se.pdf;
+        ret.flags |= se.flags;
+    }
+    return ret;
+}
+// MaterialEvaluator::evaluate (material.cpp:132-148)
+VD ScatterEval mat_evaluate(const DScene &S, const MatCtx &mc, const Interaction &it, V3 wi, DCounters &cnt) {
+    ScatterEval ret = mat_evaluate_world(S, mc, it, it.wo, wi, nullptr, cnt);
+    bool discard = same_hemisphere(it.wo, wi, it.ng) == ((ret.flags & flag::Transmission) != 0);
+    if (discard) ret.pdf = 0.f;
+    return ret;
+}
+// MaterialEvaluator::sample -> Lobe::sample / LobeSet::sample_wi_impl (material.cpp:166-184, lobe.cpp:111-119,629-658)
+VD BSDFSample mat_sample(const DScene &S, const MatCtx &mc, const Interaction &it, Sampler &sampler, DCounters &cnt) {
+    BSDFSample ret; ret.eta = 1.f;
+    V3 wo = it.shading.to_local(it.wo);
+    bool valid;
+    V3 wi_local;
+    if (mc.is_set) {
+        float uc = sampler.next_1d();
+        (void) sampler.next_2d();
+        int strategy = 0;
+        float sum_weights = 0.f;
+        for (int i = 0; i < mc.n; ++i) {
+            float sw;
+            if (mc.m->type == VMK_MAT_MIX) sw = mc.mixw[i];
+            else { int k = i + mc.first; sw = k == 0 ? mc.sw[0] : k == 1 ? mc.sw[1] : k == 2 ? mc.sw[2] : k == 3 ? mc.sw[3] : k == 4 ? mc.sw[4] : mc.sw[5]; }
+            strategy = uc > sum_weights ? i : strategy;
+            sum_weights += sw;
+        }
+        Lobe l; mat_lobe(S, mc, it, mc.n == 1 ? 0 : strategy, l, cnt);
+        wi_local = sample_wi_local(l, wo, sampler, &valid);
+    } else {
+        wi_local = sample_wi_local(mc.single, wo, sampler, &valid);
+    }
+    ret.wi = it.shading.to_world(wi_local);
+    ret.eval = mat_evaluate_world(S, mc, it, it.wo, ret.wi, &ret.eta, cnt);
+    ret.eval.pdf *= valid ? 1.f : 0.f;
+    bool discard = same_hemisphere(it.wo, ret.wi, it.ng) == ((ret.eval.flags & flag::Transmission) != 0);
+    if (discard) ret.eval.pdf = 0.f;
+    return ret;
+}
+
+// =====================================================================================================
+// a7-a10. lights — base/illumination/lightsampler.cpp, render_core/light/{area,environments/spherical}.cpp,
+//                  render_core/warper/{alias.h,alias2d.cpp}
+// =====================================================================================================
+struct LightEval { V3 L; float pdf; };
+struct LightSample { LightEval eval; V3 p_light; };
+
+VD void alias_offset_u_remapped(const DScene &S, uint32_t base, uint32_t size, float u, uint32_t *idx_out, float *u_remapped) { // alias.h:148-158
+    u = u * (float) size;
+    uint32_t idx = min((uint32_t) u, size - 1u);
+    u = fmin_(u - (float) idx, OneMinusEpsilon);
+    float prob = S.alias_prob[base + idx];
+    uint32_t alias = S.alias_idx[base + idx];
+    *u_remapped = u < prob ? fmin_(u / prob, OneMinusEpsilon) : fmin_((1.f - u) / (1.f - prob), OneMinusEpsilon);
+    *idx_out = u < prob ? idx : alias;
+}
+VD float alias_PMF(const DScene &S, const vmk_light *l, uint32_t i) { // alias.h:50-52
+    return l->alias_integral > 0.f ? S.alias_func[l->alias_offset + i] / (l->alias_integral * (float) l->alias_count) : 0.f;
+}
+VD float alias_PDF(const DScene &S, const vmk_light *l, uint32_t i) { // alias.h:44-46
+    return l->alias_integral > 0.f ? S.alias_func[l->alias_offset + i] / l->alias_integral : 0.f;
+}
+VD float light_select_PMF(const DScene &S, const vmk_render_params *P, uint32_t index) { // lightsampler.cpp:159-176, uniform.cpp:13-20
+    uint32_t n = S.n_lights;
+    if (P->env_separate && S.env_light != VMK_INVALID) {
+        float env_prob = P->env_prob;
+        uint32_t punctual = n - 1u;
+        if (index == S.env_light) return env_prob;
+        return (1.f - env_prob) * (1.f / (float) punctual);
+    }
+    return 1.f / (float) n;
+}
+VD void light_select(const DScene &S, const vmk_render_params *P, float u, uint32_t *index, float *pmf) { // lightsampler.cpp:178-197, uniform.cpp:23-34
+    uint32_t n = S.n_lights;
+    if (P->env_separate && S.env_light != VMK_INVALID) {
+        float env_prob = P->env_prob;
+        if (u < env_prob) { *index = S.env_light; *pmf = env_prob; return; }
+        u = remapping(u, env_prob, 1.f);
+        uint32_t punctual = n - 1u;
+        uint32_t idx = (uint32_t) fmin_(u * (float) punctual, (float) punctual - 1.f);
+        idx = idx < S.env_light ? idx : idx + 1u;
+        *index = idx; *pmf = (1.f / (float) punctual) * (1.f - env_prob);
+        return;
+    }
+    *index = (uint32_t) fmin_(u * (float) n, (float) n - 1.f);
+    *pmf = 1.f / (float) n;
+}
+VD V3 area_L(const DScene &S, const vmk_light *l, V2 uv, V3 ng, V3 w, DCounters &cnt) { // area.cpp:91-95
+    V3 radiance = eval_slot3(S, l->color, uv, cnt) * l->scale;
+    return radiance * ((dot(w, ng) > 0.f || l->two_sided) ? 1.f : 0.f);
+}
+VD float area_PDF_wi(float pdf_pos, V3 ng, V3 w) { // area.cpp:114-118
+    float ret = PDF_wi(pdf_pos, ng, w);
+    return (isinf_(ret) || isnan_(ret)) ? 0.f : ret;
+}
+VD LightSample area_sample_wi(const DScene &S, const vmk_render_params *P, const vmk_light *l, V3 p_ref, V2 u, DCounters &cnt) { // area.cpp:120-149
+    uint32_t prim; float ur;
+    alias_offset_u_remapped(S, l->alias_offset, l->alias_count, u.x, &prim, &ur);
+    float pmf = alias_PMF(S, l, prim);
+    u.x = ur;
+    V2 bary = square_to_triangle(u);
+    uint32_t tri = S.tri_lookup[S.instances[l->inst_id].tri_offset + prim];
+    Interaction it;
+    compute_surface_interaction<false>(S, tri, l->inst_id, prim, bary, it);
+    float pdf_pos = (1.f / it.prim_area) * pmf;
+    LightSample ret;
+    V3 w = p_ref - it.pos;
+    ret.eval.L = area_L(S, l, it.uv, it.ng, w, cnt);
+    ret.eval.pdf = area_PDF_wi(pdf_pos, it.ng, w);
+    ret.p_light = robust_pos(it.pos, it.ng, w, P->ray_offset_factor);
+    return ret;
+}
+VD V3 env_L(const DScene &S, const vmk_light *l, V3 local_dir, DCounters &cnt) { // spherical.cpp:60-68
+    V2 uv = {spherical_phi(local_dir) * Inv2Pi, spherical_theta(local_dir) * InvPi};
+    return eval_slot3(S, l->color, uv, cnt) * l->scale;
+}
+VD float env_map_PDF(const DScene &S, const vmk_light *l, V2 p) { // alias2d.cpp:102-106
+    uint32_t iu = min((uint32_t) (p.x * (float) l->res_x), l->res_x - 1u);
+    uint32_t iv = min((uint32_t) (p.y * (float) l->res_y), l->res_y - 1u);
+    return l->alias_integral > 0.f ? S.alias_func[l->cond_offset + iv * l->res_x + iu] / l->alias_integral : 0.f;
+}
+VD LightEval env_evaluate_wi(const DScene &S, const vmk_light *l, V3 p_ref_pos, V3 p_light_pos, DCounters &cnt) { // spherical.cpp:86-103
+    LightEval ret;
+    V3 world_dir = normalize(p_light_pos - p_ref_pos);
+    V3 local_dir = mul3x3(l->w2o, world_dir);
+    float theta = spherical_theta(local_dir), phi = spherical_phi(local_dir);
+    float sin_t = sin_(theta);
+    V2 uv = {phi * Inv2Pi, theta * InvPi};
+    ret.L = env_L(S, l, local_dir, cnt);
+    float pdf = env_map_PDF(S, l, uv) / (_2Pi * Pi * sin_t);
+    ret.pdf = sin_t == 0.f ? 0.f : pdf;
+    return ret;
+}
+VD LightSample env_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, V2 u, DCounters &cnt) { // spherical.cpp:105-125,162-168; alias2d.cpp:110-129
+    uint32_t iv; float urv;
+    alias_offset_u_remapped(S, l->alias_offset, l->alias_count, u.y, &iv, &urv);
+    float fv = ((float) iv + urv) / (float) l->alias_count;
+    float pdf_v = alias_PDF(S, l, iv);
+    uint32_t buffer_offset = l->res_x * iv;
+    uint32_t iu; float uru;
+    alias_offset_u_remapped(S, l->cond_offset + buffer_offset, l->res_x, u.x, &iu, &uru);
+    float fu = ((float) iu + uru) / (float) l->res_x;
+    float integral_u = S.alias_func[l->alias_offset + iv];
+    float func_u = S.alias_func[l->cond_offset + buffer_offset + iu];
+    float pdf_u = integral_u > 0.f ? func_u / integral_u : 0.f;
+    float pdf_map = pdf_u * pdf_v;
+    LightSample ret;
+    float theta = fv * Pi, phi = fu * _2Pi;
+    float sin_t, cos_t; sincos_(theta, &sin_t, &cos_t);
+    V3 local_dir = spherical_direction(sin_t, cos_t, phi);
+    V3 world_dir = normalize(mul3x3(l->o2w, local_dir));
+    float pdf_dir = pdf_map / (_2Pi * Pi * sin_t);
+    ret.eval.pdf = isinf_(pdf_dir) ? 0.f : pdf_dir;
+    ret.eval.L = env_L(S, l, local_dir, cnt);
+    ret.p_light = p_ref + world_dir * l->world_diameter;
+    return ret;
+}
+VD LightSample light_sample_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, Sampler &sampler, DCounters &cnt) { // lightsampler.cpp:199-216
+    float u_light = sampler.next_1d();
+    V2 u_surface = sampler.next_2d();
+    uint32_t index; float pmf;
+    light_select(S, P, u_light, &index, &pmf);
+    const vmk_light *l = S.lights + index;
+    LightSample ls = l->type == VMK_LIGHT_AREA ? area_sample_wi(S, P, l, p_ref, u_surface, cnt) : env_sample_wi(S, l, p_ref, u_surface, cnt);
+    ls.eval.pdf *= pmf;
+    return ls;
+}
+VD LightEval light_evaluate_hit_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, const Interaction &it, DCounters &cnt) { // lightsampler.cpp:252-267
+    LightEval ret; ret.L = mk3(0.f); ret.pdf = 0.f;
+    const vmk_light *l = S.lights + it.light_id;
+    if (l->type != VMK_LIGHT_AREA) return ret;
+    float pdf_pos = (1.f / it.prim_area) * alias_PMF(S, l, it.prim_id);
+    V3 w = p_ref - it.pos;
+    ret.L = area_L(S, l, it.uv, it.ng, w, cnt);
+    ret.pdf = area_PDF_wi(pdf_pos, it.ng, w);
+    ret.pdf *= light_select_PMF(S, P, it.light_id);
+    return ret;
+}
+VD LightEval light_evaluate_miss_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, V3 wi, DCounters &cnt) { // lightsampler.cpp:290-300
+    const vmk_light *l = S.lights + S.env_light;
+    LightEval ret = env_evaluate_wi(S, l, p_ref, p_ref + wi, cnt);
+    ret.pdf *= light_select_PMF(S, P, S.env_light);
+    return ret;
+}
+
+// =====================================================================================================
+// a3. ray generation — sampler.h:65-73, box.cpp:16-20, triangle.cpp:16-18, fitted_curve.h:76-113,
+//     sensor.cpp:44-56, thin_lens.cpp:34-42
+// =====================================================================================================
+VD void table_offset(const float *prob, const uint32_t *alias, uint32_t size, float u, uint32_t *idx_out, float *u_remapped) {
+    u = u * (float) size;
+    uint32_t idx = min((uint32_t) u, size - 1u);
+    u = fmin_(u - (float) idx, OneMinusEpsilon);
+    float p = prob[idx];
+    *u_remapped = u < p ? fmin_(u / p, OneMinusEpsilon) : fmin_((1.f - u) / (1.f - p), OneMinusEpsilon);
+    *idx_out = u < p ? idx : alias[idx];
+}
+VD V2 filter_sample(const vmk_render_params *P, V2 u) {
+    if (P->filter_type == VMK_FILTER_BOX) return {lerp_(u.x, -P->filter_radius[0], P->filter_radius[0]), lerp_(u.y, -P->filter_radius[1], P->filter_radius[1])};
+    if (P->filter_type == VMK_FILTER_TRIANGLE) return {sample_tent(u.x, P->filter_radius[0]), sample_tent(u.y, P->filter_radius[1])};
+    const uint32_t N = VMK_FILTER_TABLE_SIZE;
+    V2 v = {u.x * 2.f - 1.f, u.y * 2.f - 1.f};
+    V2 a = {abs_(v.x), abs_(v.y)};
+    uint32_t iv; float urv; table_offset(P->filter_marginal_prob, P->filter_marginal_alias, N, a.y, &iv, &urv);
+    float fv = ((float) iv + urv) / (float) N;
+    uint32_t iu; float uru; table_offset(P->filter_cond_prob + iv * N, P->filter_cond_alias + iv * N, N, a.x, &iu, &uru);
+    float fu = ((float) iu + uru) / (float) N;
+    float sx = v.x > 0.f ? 1.f : (v.x < 0.f ? -1.f : 0.f), sy = v.y > 0.f ? 1.f : (v.y < 0.f ? -1.f : 0.f);
+    return {fu * sx * P->filter_radius[0], fv * sy * P->filter_radius[1]};
+}
+VD Ray generate_ray(const vmk_render_params *P, uint32_t px, uint32_t py, Sampler &sampler) {
+    V2 fs = filter_sample(P, sampler.next_2d());
+    V2 p_film = {(float) px + 0.5f + fs.x, (float) py + 0.5f + fs.y};
+    V2 p_lens_u = sampler.next_2d();
+    (void) sampler.next_1d();
+    V3 p_sensor = transform_point4(P->raster_to_sensor, mk3(p_film.x, p_film.y, 0.f));
+    V3 dir = normalize(p_sensor);
+    V2 pl = square_to_disk(p_lens_u) * P->lens_radius;
+    float ft = P->focal_distance / dir.z;
+    V3 p_focus = dir * ft;
+    V3 org = mk3(pl.x, pl.y, 0.f);
+    dir = normalize(p_focus - org);
+    Ray r;
+    r.o = transform_point4(P->c2w, org);
+    r.d = transform_vector4(P->c2w, dir);
+    r.t_max = RayTMax;
+    return r;
+}
+
+}// namespace vmkd

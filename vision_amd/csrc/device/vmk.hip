@@ -1,0 +1,883 @@
+// vmk.hip — libvmk.so: the gfx950 path-tracing backend behind include/vmk.h.
+//
+// Kernels (all hand-written HIP, wave64):
+//   k_render         the megakernel: ray-gen -> LDS-stack BVH traversal -> polymorphic BSDF eval/sample -> NEE ->
+//                    Russian roulette -> in-register film accumulation; persistent lanes pull (pixel) work items with
+//                    a wavefront ballot so finished lanes are refilled instead of idling.
+//   k_morton / k_karras / k_refit / k_emit   GPU LBVH build (Morton codes -> radix sort -> Karras hierarchy -> refit)
+//   k_trace          traversal-only replay over SoA ray buffers (roofline measurement, parity of hits)
+//   k_tonemap        exposure / tone map / gamma epilogue
+//   k_test           per-function device unit entry points for the parity tests
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dbvh.h"
+
+using namespace vmkd;
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) { ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); return VMK_ERR_HIP; } \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kDefaultTile = 32;
+
+// ---------------------------------------------------------------------------------------------------------
+// LBVH build
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__global__ void k_morton(const vmk_tri_pos *tris, uint32_t n, float3 bmin, float3 inv_ext, uint64_t *keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const vmk_tri_pos &t = tris[i];
+    float c[3];
+    for (int a = 0; a < 3; ++a) {
+        float lo = fminf(t.p0[a], fminf(t.p1[a], t.p2[a])), hi = fmaxf(t.p0[a], fmaxf(t.p1[a], t.p2[a]));
+        c[a] = 0.5f * (lo + hi);
+    }
+    float x = fminf(fmaxf((c[0] - bmin.x) * inv_ext.x * 1024.f, 0.f), 1023.f);
+    float y = fminf(fmaxf((c[1] - bmin.y) * inv_ext.y * 1024.f, 0.f), 1023.f);
+    float z = fminf(fmaxf((c[2] - bmin.z) * inv_ext.z * 1024.f, 0.f), 1023.f);
+    uint32_t m = (expand_bits10((uint32_t) x) << 2) | (expand_bits10((uint32_t) y) << 1) | expand_bits10((uint32_t) z);
+    keys[i] = ((uint64_t) m << 32) | (uint64_t) i;
+}
+__global__ void k_reorder(const uint64_t *keys, uint32_t n, const vmk_tri_pos *pos_in, const vmk_tri_attr *attr_in,
+                          vmk_tri_pos *pos_out, vmk_tri_attr *attr_out, uint32_t *lookup) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t src = (uint32_t) (keys[i] & 0xffffffffull);
+    pos_out[i] = pos_in[src];
+    attr_out[i] = attr_in[src];
+    lookup[src] = i;
+}
+__device__ __forceinline__ int delta_key(const uint64_t *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long) (keys[i] ^ keys[j]));
+}
+// Karras 2012, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees": one thread per internal node.
+__global__ void k_karras(const uint64_t *keys, int n, int2 *children, int2 *ranges, int *parent_internal, int *parent_leaf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta_key(keys, n, i, i + 1) - delta_key(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta_key(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta_key(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2) if (delta_key(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta_key(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta_key(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    int gamma = i + s * d + min(d, 0);
+    int first = min(i, j), last = max(i, j);
+    // child encoding in the build arrays: >= 0 internal, < 0 leaf ~index
+    int left = (first == gamma) ? ~gamma : gamma;
+    int right = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    children[i] = make_int2(left, right);
+    ranges[i] = make_int2(first, last);
+    if (left >= 0) parent_internal[left] = i; else parent_leaf[gamma] = i;
+    if (right >= 0) parent_internal[right] = i; else parent_leaf[gamma + 1] = i;
+    if (i == 0) parent_internal[0] = -1;
+}
+// bottom-up AABB refit: the second thread to reach a node merges its children; also records the tree depth
+__global__ void k_refit(const vmk_tri_pos *tris, int n, const int2 *children, const int *parent_internal, const int *parent_leaf,
+                        float *leaf_box, float *node_box, int *flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const vmk_tri_pos &t = tris[i];
+    float b[6];
+    for (int a = 0; a < 3; ++a) { b[a] = fminf(t.p0[a], fminf(t.p1[a], t.p2[a])); b[3 + a] = fmaxf(t.p0[a], fmaxf(t.p1[a], t.p2[a])); }
+    for (int a = 0; a < 6; ++a) __hip_atomic_store(leaf_box + (size_t) i * 6 + a, b[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == 1) return;
+    __threadfence();
+    int node = parent_leaf[i];
+    while (node >= 0) {
+        if (atomicAdd(&flags[node], 1) == 0) return; // first arrival: sibling subtree not finished
+        __threadfence();
+        int2 c = children[node];
+        const float *lb = c.x >= 0 ? node_box + (size_t) c.x * 6 : leaf_box + (size_t) (~c.x) * 6;
+        const float *rb = c.y >= 0 ? node_box + (size_t) c.y * 6 : leaf_box + (size_t) (~c.y) * 6;
+        float nb[6];
+        // agent-scope (sc1) loads/stores: the sibling's box was written by another CU (per-CU L1s are not coherent)
+        auto ld = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        for (int a = 0; a < 3; ++a) { nb[a] = fminf(ld(lb + a), ld(rb + a)); nb[3 + a] = fmaxf(ld(lb + 3 + a), ld(rb + 3 + a)); }
+        for (int a = 0; a < 6; ++a) __hip_atomic_store(node_box + (size_t) node * 6 + a, nb[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        node = parent_internal[node];
+    }
+}
+__global__ void k_depth(int n, const int *parent_internal, const int *parent_leaf, const int2 *ranges, int *max_depth) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int depth = 0;
+    int node = n > 1 ? parent_leaf[i] : -1;
+    while (node >= 0) { int2 r = ranges[node]; if (r.y - r.x + 1 > kMaxLeafTris) ++depth; node = parent_internal[node]; }
+    atomicMax(max_depth, depth);
+}
+__device__ __forceinline__ int32_t encode_child(int c, const int2 *ranges) {
+    if (c < 0) { uint32_t leaf = (uint32_t) (~c); return (int32_t) ~(leaf & kLeafFirstMask); } // single triangle
+    int2 r = ranges[c];
+    int count = r.y - r.x + 1;
+    if (count <= kMaxLeafTris) return (int32_t) ~(((uint32_t) r.x & kLeafFirstMask) | ((uint32_t) (count - 1) << 28));
+    return c;
+}
+// final 64 B nodes: child boxes pulled into the parent, subtrees of <= kMaxLeafTris triangles collapsed into leaves
+__global__ void k_emit(int n, const int2 *children, const int2 *ranges, const float *leaf_box, const float *node_box, BvhNode *out, uint32_t *n_leaves) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int2 c = children[i];
+    const float *lb = c.x >= 0 ? node_box + (size_t) c.x * 6 : leaf_box + (size_t) (~c.x) * 6;
+    const float *rb = c.y >= 0 ? node_box + (size_t) c.y * 6 : leaf_box + (size_t) (~c.y) * 6;
+    BvhNode nd;
+    for (int a = 0; a < 3; ++a) { nd.lmin[a] = lb[a]; nd.lmax[a] = lb[3 + a]; nd.rmin[a] = rb[a]; nd.rmax[a] = rb[3 + a]; }
+    nd.left = encode_child(c.x, ranges); nd.right = encode_child(c.y, ranges);
+    nd.pad0 = nd.pad1 = 0;
+    out[i] = nd;
+    int2 r = ranges[i];
+    if (r.y - r.x + 1 > kMaxLeafTris) { // live node: count its leaf children
+        uint32_t k = (nd.left < 0 ? 1u : 0u) + (nd.right < 0 ? 1u : 0u);
+        if (k) atomicAdd(n_leaves, k);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// one path vertex: IlluminationIntegrator::Li loop body (base/integral/integrator.cpp:160-311), no media
+// ---------------------------------------------------------------------------------------------------------
+struct PathState {
+    Ray ray;
+    V3 L, T, prev_ng;
+    float scatter_pdf, eta_scale;
+    uint32_t bounces;
+};
+__device__ __forceinline__ void path_begin(PathState &ps) {
+    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
+}
+// returns true when the path ends at this vertex.  `dbg` (tests only): 8 floats per vertex.
+__device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, uint32_t *stack, PathState &ps, Sampler &sampler,
+                                            DCounters &cnt, float *dbg) {
+    const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
+    if (max_depth == 0) return true; // `$for(&bounces, 0, max_depth)` never runs
+    Hit hit;
+    cnt.closest++;
+    bool found = traverse<false>(S, ps.ray, stack, kBlock, hit, cnt);
+    if (dbg) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
+    if (!found) { // evaluate_miss integrator.cpp:137-158
+        if (S.env_light != VMK_INVALID) {
+            LightEval ev = light_evaluate_miss_wi(S, P, ps.ray.o, ps.ray.d, cnt);
+            float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
+            weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
+            ps.L += (ev.L * 1.f * weight) * ps.T;
+        }
+        return true;
+    }
+    Interaction it;
+    compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
+    it.wo = normalize(-ps.ray.d);
+    if (it.mat_id == VMK_INVALID) { // integrator.cpp:208-214: pass through, bounce not counted
+        ps.ray = spawn_ray(it.pos, it.ng, ps.ray.d);
+        return false;
+    }
+    cnt.hits++;
+    if (it.light_id != VMK_INVALID) { // integrator.cpp:221-231
+        LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt);
+        float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
+        weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
+        ps.L += ev.L * ps.T * weight * 1.f;
+    }
+    ps.prev_ng = it.ng;
+    // NEE (3 draws) + shadow ray
+    LightSample ls = light_sample_wi(S, P, it.pos, sampler, cnt);
+    Ray shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
+    Hit sh;
+    cnt.shadow++;
+    bool occluded = traverse<true>(S, shadow_ray, stack, kBlock, sh, cnt);
+    // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
+    MatCtx mc;
+    mat_prepare(S, S.materials + it.mat_id, it, mc, cnt);
+    V3 wi = normalize(ls.p_light - it.pos);
+    ScatterEval se = mat_evaluate(S, mc, it, wi, cnt);
+    BSDFSample bs = mat_sample(S, mc, it, sampler, cnt);
+    if (dbg) { dbg[4] = ls.eval.pdf; dbg[5] = se.pdf; dbg[6] = bs.eval.pdf; dbg[7] = occluded ? 1.f : 0.f; }
+    bool is_delta_light = ls.eval.pdf < 0.f;
+    float weight = mis_mode != 1 ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, se.pdf)) : 1.f;
+    ls.eval.pdf = is_delta_light ? -ls.eval.pdf : ls.eval.pdf;
+    V3 Ld = mk3(0.f);
+    if (!occluded && se.pdf > 0.f && ls.eval.pdf > 0.f) Ld = ls.eval.L * se.f * weight / ls.eval.pdf;
+    if (mis_mode == 2) Ld = Ld * 0.f;
+    ps.L += ps.T * Ld * 1.f;
+    ps.eta_scale *= sqr(bs.eta);
+    float lum = max_comp(ps.T);
+    if (!(bs.eval.pdf > 0.f) || lum == 0.f) return true;
+    ps.T *= bs.eval.f / bs.eval.pdf;
+    if (ps.eta_scale * lum < P->rr_threshold && ps.bounces >= min_depth) { // integrator.cpp:292-299
+        float q = fmin_(0.95f, lum);
+        float rr = sampler.next_1d();
+        if (q < rr) return true;
+        ps.T = ps.T / q;
+    }
+    ps.scatter_pdf = bs.eval.pdf;
+    ps.ray = spawn_ray(it.pos, it.ng, bs.wi);
+    ++ps.bounces;
+    return ps.bounces >= max_depth;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the megakernel
+// ---------------------------------------------------------------------------------------------------------
+struct RenderArgs {
+    const DScene *scene;
+    const vmk_render_params *params;
+    float4 *accum;
+    uint32_t *queue;      // work-item counter
+    unsigned long long *counters; // 7 x u64 (vmk_counters layout)
+    uint32_t frame_begin, frame_count;
+    uint32_t tile_size, tile_shift, tiles_x, tiles_y, rank, world, n_work;
+};
+
+__device__ __forceinline__ uint32_t compact_bits(uint32_t v) { // inverse of 2-D Morton interleave (even bits)
+    v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; v = (v | (v >> 8)) & 0x0000FFFFu;
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_render(RenderArgs A) {
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    const DScene S = *A.scene;
+    const vmk_render_params *P = A.params;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *stack = s_stack + threadIdx.x;
+    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+
+    const uint32_t frame_end = A.frame_begin + A.frame_count;
+
+    // per-lane persistent state
+    bool has_pixel = false, queue_empty = false, path_alive = false;
+    uint32_t px = 0, py = 0, frame = 0;
+    V4 acc = {0.f, 0.f, 0.f, 0.f};
+    Sampler sampler; sampler.state = 0;
+    PathState ps;
+    ps.ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
+    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.prev_ng = mk3(0.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.bounces = 0;
+
+    for (;;) {
+        // ---- refill idle lanes with new pixels (wavefront ballot + one atomic per wave) ----
+        bool need = !has_pixel && !queue_empty;
+        unsigned long long need_mask = __ballot(need);
+        if (need_mask) {
+            uint32_t n_need = (uint32_t) __popcll(need_mask);
+            uint32_t base = 0;
+            int leader = __ffsll((long long) need_mask) - 1;
+            if ((int) lane == leader) base = atomicAdd(A.queue, n_need);
+            base = __shfl(base, leader, 64);
+            if (need) {
+                uint32_t w = base + (uint32_t) __popcll(need_mask & ((1ull << lane) - 1ull));
+                if (w >= A.n_work) queue_empty = true;
+                else {
+                    uint32_t per_tile = A.tile_size * A.tile_size;
+                    uint32_t k = w >> (2u * A.tile_shift), r = w & (per_tile - 1u);
+                    uint32_t tile = A.rank + k * A.world;
+                    uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+                    px = tx * A.tile_size + compact_bits(r); py = ty * A.tile_size + compact_bits(r >> 1);
+                    if (px < P->width && py < P->height) {
+                        has_pixel = true; frame = A.frame_begin; path_alive = false;
+                        float4 a = A.accum[(size_t) py * P->width + px];
+                        acc = {a.x, a.y, a.z, a.w};
+                    }
+                }
+            }
+        }
+        if (!__any(has_pixel || !queue_empty)) break;
+        if (!has_pixel) continue;
+
+        // ---- start a new path: ray generation (rt_geom kernel of the reference, frame_buffer.cpp:172-177) ----
+        if (!path_alive) {
+            sampler.start(px, py, frame, 0);
+            ps.ray = generate_ray(P, px, py, sampler);
+            sampler.start(px, py, frame, 1); // path_tracing kernel, integrator.cpp:93
+            path_begin(ps);
+            path_alive = true;
+            cnt.paths++;
+        }
+
+        // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
+        bool terminate = path_bounce(S, P, stack, ps, sampler, cnt, nullptr);
+        if (terminate) { // RGBFilm accumulation, frame_buffer.cpp:117-126
+            float a = 1.f / (float) (frame + 1u);
+            V4 val = {ps.L.x, ps.L.y, ps.L.z, 1.f};
+            acc = lerp4(a, acc, val);
+            path_alive = false;
+            ++frame;
+            if (frame >= frame_end) {
+                A.accum[(size_t) py * P->width + px] = make_float4(acc.x, acc.y, acc.z, acc.w);
+                has_pixel = false;
+            }
+        }
+    }
+    // ---- counters: one atomic per wave and counter ----
+    uint32_t c[7] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris, cnt.paths, cnt.hits, cnt.tex};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        uint32_t s = wave_sum(c[i]);
+        if (lane == 0 && s) atomicAdd(A.counters + i, (unsigned long long) s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// traversal replay, tone map, unit tests
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_trace(const DScene *scene, uint32_t n, const float *org, const float *dir, const float *tmax,
+                                                  int any_hit, uint32_t *hit_out, unsigned long long *counters) {
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    const DScene S = *scene;
+    uint32_t *stack = s_stack + threadIdx.x;
+    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        // SoA rays: component arrays of length n (coalesced 4 B/lane loads)
+        Ray r = {mk3(org[i], org[n + i], org[2 * n + i]), mk3(dir[i], dir[n + i], dir[2 * n + i]), tmax[i]};
+        Hit h;
+        uint4 o;
+        if (any_hit) { cnt.shadow++; bool occ = traverse<true>(S, r, stack, kBlock, h, cnt); o = make_uint4(occ ? 1u : 0u, 0, 0, 0); }
+        else { cnt.closest++; traverse<false>(S, r, stack, kBlock, h, cnt); o = make_uint4(h.inst, h.prim, f2u(h.bary.x), f2u(h.bary.y)); }
+        reinterpret_cast<uint4 *>(hit_out)[i] = o;
+    }
+    uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
+    for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
+}
+
+__device__ __forceinline__ float tone1(uint32_t tm, float x) { // tonemapper/impl.cpp:16-45
+    if (tm == 1) { float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f; return saturate_((x * (a * x + b)) / (x * (c * x + d) + e)); }
+    if (tm == 2) return x / (x + 1.f);
+    return x;
+}
+__global__ void k_tonemap(const float4 *accum, float4 *out, uint32_t n, float exposure, uint32_t tm, int final_picture) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = accum[i];
+    float v[3] = {a.x, a.y, a.z};
+    for (int c = 0; c < 3; ++c) {
+        float x = 1.f - exp_(-v[c] * exposure); // frame_buffer.cpp:72-74
+        x = tone1(tm, x);
+        if (final_picture) { // Pipeline::final_picture applies the tone mapper again + sRGB (pipeline.cpp:337-354, postprocessor.cpp:13-30)
+            x = tone1(tm, x);
+            x = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(x, 1.f / 2.4f) - 0.055f;
+        }
+        v[c] = x;
+    }
+    out[i] = make_float4(v[0], v[1], v[2], 1.f);
+}
+
+__global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *a = in + (size_t) i * in_stride;
+    float *o = out + (size_t) i * out_stride;
+    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+    switch (kind) {
+        case 0: { Sampler s; s.start(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3])); for (int k = 0; k < 8; ++k) o[k] = s.next_1d(); break; }
+        case 1: {
+            float s, c; sincos_(a[0], &s, &c);
+            o[0] = s; o[1] = c; o[2] = acos_(clamp_(a[0], -1.f, 1.f)); o[3] = atan2_(a[1], a[0]); o[4] = exp_(-abs_(a[0])); o[5] = sqrt_(abs_(a[0]));
+            break;
+        }
+        case 2: {
+            V2 u = {a[0], a[1]};
+            V2 d = square_to_disk(u); V3 c = square_to_cosine_hemisphere(u); V2 t = square_to_triangle(u);
+            o[0] = d.x; o[1] = d.y; o[2] = c.x; o[3] = c.y; o[4] = c.z; o[5] = t.x; o[6] = t.y; o[7] = sample_tent(a[0], 0.5f);
+            break;
+        }
+        case 3: {
+            V3 wo = normalize(mk3(a[0], a[1], a[2]));
+            V3 wh = sample_wh(wo, {a[3], a[4]}, a[5], a[6]);
+            o[0] = wh.x; o[1] = wh.y; o[2] = wh.z; o[3] = bsdf_D(wh, a[5], a[6]); o[4] = bsdf_G1(wo, a[5], a[6]);
+            o[5] = PDF_wh(wo, wh, a[5], a[6]); o[6] = fresnel_dielectric(abs_dot(wo, wh), a[7]); o[7] = fresnel_complex(abs_dot(wo, wh), a[7], 3.5f);
+            break;
+        }
+        case 4: {
+            const DScene S = *scene;
+            uint32_t mat_id = f2u(a[0]);
+            Interaction it;
+            it.pos = mk3(0.f); it.ng = mk3(0, 0, 1);
+            it.shading = {mk3(1, 0, 0), mk3(0, 1, 0), mk3(0, 0, 1)};
+            it.wo = normalize(mk3(a[4], a[5], a[6]));
+            it.uv = {a[10], a[11]};
+            it.mat_id = mat_id; it.light_id = VMK_INVALID; it.prim_id = 0; it.prim_area = 1.f;
+            V3 wi = normalize(mk3(a[7], a[8], a[9]));
+            MatCtx mc; mat_prepare(S, S.materials + mat_id, it, mc, cnt);
+            ScatterEval se = mat_evaluate(S, mc, it, wi, cnt);
+            Sampler smp; smp.start(f2u(a[1]), f2u(a[2]), f2u(a[3]), 1);
+            BSDFSample bs = mat_sample(S, mc, it, smp, cnt);
+            o[0] = se.f.x; o[1] = se.f.y; o[2] = se.f.z; o[3] = se.pdf; o[4] = u2f(se.flags);
+            o[5] = bs.wi.x; o[6] = bs.wi.y; o[7] = bs.wi.z; o[8] = bs.eval.f.x; o[9] = bs.eval.f.y; o[10] = bs.eval.f.z; o[11] = bs.eval.pdf; o[12] = bs.eta;
+            break;
+        }
+        case 5: {
+            Sampler s; s.start(f2u(a[0]), f2u(a[1]), f2u(a[2]), 0);
+            Ray r = generate_ray(P, f2u(a[0]), f2u(a[1]), s);
+            o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+            break;
+        }
+        case 6: { // whole path of one (pixel, frame): 8 floats per vertex for up to 8 vertices, then L (3 floats)
+            extern __shared__ uint32_t s_dyn_stack[];
+            const DScene S = *scene;
+            uint32_t px = f2u(a[0]), py = f2u(a[1]), frame = f2u(a[2]);
+            Sampler smp; smp.start(px, py, frame, 0);
+            PathState ps; ps.ray = generate_ray(P, px, py, smp);
+            smp.start(px, py, frame, 1);
+            path_begin(ps);
+            for (int v = 0; v < 64; ++v) {
+                float dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                bool end = path_bounce(S, P, s_dyn_stack + threadIdx.x, ps, smp, cnt, dbg);
+                if (v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
+                if (end) break;
+            }
+            o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z;
+            break;
+        }
+        default: break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// context + C-ABI
+// ---------------------------------------------------------------------------------------------------------
+template<typename T>
+struct DevBuf {
+    T *p{nullptr};
+    size_t n{0};
+    hipError_t alloc(size_t count) { release(); n = count; if (!count) return hipSuccess; return hipMalloc((void **) &p, count * sizeof(T)); }
+    hipError_t upload(const T *src, size_t count, hipStream_t s) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || !count) return e;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
+};
+
+struct vmk_ctx {
+    int device{0};
+    hipStream_t stream{nullptr};
+    hipEvent_t ev0{nullptr}, ev1{nullptr};
+    std::string error;
+    int n_cus{256};
+    // scene
+    bool scene_ready{false}, accel_ready{false}, params_ready{false};
+    uint32_t n_tris{0};
+    DevBuf<vmk_tri_pos> tri_pos_in, tri_pos;
+    DevBuf<vmk_tri_attr> tri_attr_in, tri_attr;
+    DevBuf<uint32_t> tri_lookup;
+    DevBuf<vmk_instance> instances;
+    DevBuf<vmk_material> materials;
+    DevBuf<vmk_light> lights;
+    DevBuf<vmk_texture> textures;
+    DevBuf<uint8_t> tex_data;
+    DevBuf<float> alias_prob, alias_func, srgb_lut, luts;
+    DevBuf<uint32_t> alias_idx;
+    DevBuf<BvhNode> nodes;
+    DevBuf<DScene> d_scene;
+    DScene h_scene{};
+    float world_min[3]{}, world_max[3]{};
+    vmk_accel_info accel{};
+    // render state
+    vmk_render_params params{};
+    DevBuf<vmk_render_params> d_params;
+    DevBuf<float4> own_fb, tm_out;
+    float4 *fb{nullptr};
+    DevBuf<uint32_t> queue;
+    DevBuf<unsigned long long> counters;
+};
+
+static thread_local std::string g_null_error;
+
+extern "C" {
+
+uint32_t vmk_abi_version(void) { return VMK_ABI_VERSION; }
+const char *vmk_last_error(const vmk_ctx *ctx) { return ctx ? ctx->error.c_str() : g_null_error.c_str(); }
+
+int vmk_create(int device, vmk_ctx **out) {
+    if (!out) return VMK_ERR_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { g_null_error = "vmk_create: no HIP device visible (this backend has no CPU fallback)"; return VMK_ERR_HIP; }
+    if (device < 0 || device >= count) { g_null_error = "vmk_create: bad device index"; return VMK_ERR_ARG; }
+    vmk_ctx *ctx = new vmk_ctx();
+    ctx->device = device;
+    auto bail = [&](hipError_t e, const char *what) { g_null_error = std::string(what) + ": " + hipGetErrorString(e); delete ctx; return VMK_ERR_HIP; };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+    if ((e = ctx->queue.alloc(1)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = ctx->counters.alloc(8)) != hipSuccess) return bail(e, "hipMalloc");
+    (void) hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream);
+    std::vector<float> srgb(256);
+    for (int i = 0; i < 256; ++i) { double c = i / 255.0; srgb[i] = (float) (c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4)); }
+    if ((e = ctx->srgb_lut.upload(srgb.data(), 256, ctx->stream)) != hipSuccess) return bail(e, "upload");
+    (void) hipStreamSynchronize(ctx->stream);
+    *out = ctx;
+    return VMK_OK;
+}
+
+void vmk_destroy(vmk_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    ctx->tri_pos_in.release(); ctx->tri_pos.release(); ctx->tri_attr_in.release(); ctx->tri_attr.release(); ctx->tri_lookup.release();
+    ctx->instances.release(); ctx->materials.release(); ctx->lights.release(); ctx->textures.release(); ctx->tex_data.release();
+    ctx->alias_prob.release(); ctx->alias_func.release(); ctx->alias_idx.release(); ctx->srgb_lut.release(); ctx->luts.release();
+    ctx->nodes.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release();
+    ctx->queue.release(); ctx->counters.release();
+    if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void *vmk_stream(vmk_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!sc || sc->abi_version != VMK_ABI_VERSION) { ctx->error = "vmk_upload_scene: null scene or ABI version mismatch"; return VMK_ERR_ARG; }
+    if (sc->n_tris == 0 || !sc->tri_pos || !sc->tri_attr || !sc->instances || !sc->materials || !sc->lights || sc->n_lights == 0) { ctx->error = "vmk_upload_scene: empty geometry / material / light tables"; return VMK_ERR_ARG; }
+    if (sc->n_tris > kLeafFirstMask) { ctx->error = "vmk_upload_scene: too many triangles for the 28-bit leaf encoding"; return VMK_ERR_ARG; }
+    // validate indices on the host: a kernel fault on this pool can reset the whole node
+    for (uint32_t i = 0; i < sc->n_instances; ++i) {
+        const vmk_instance &in = sc->instances[i];
+        if ((in.mat_id != VMK_INVALID && in.mat_id >= sc->n_materials) || (in.light_id != VMK_INVALID && in.light_id >= sc->n_lights) || (uint64_t) in.tri_offset + in.tri_count > sc->n_tris) { ctx->error = "vmk_upload_scene: instance table references out-of-range rows"; return VMK_ERR_ARG; }
+    }
+    for (uint32_t i = 0; i < sc->n_tris; ++i) if (sc->tri_pos[i].inst >= sc->n_instances) { ctx->error = "vmk_upload_scene: triangle references a missing instance"; return VMK_ERR_ARG; }
+    auto slot_ok = [&](const vmk_slot &s) { return s.tex == VMK_INVALID || (s.tex & 0xffffu) < sc->n_textures; };
+    for (uint32_t i = 0; i < sc->n_materials; ++i) {
+        const vmk_material &m = sc->materials[i];
+        if (m.type > VMK_MAT_MIX) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
+        for (auto &s : m.slot) if (!slot_ok(s)) { ctx->error = "vmk_upload_scene: material slot references a missing texture"; return VMK_ERR_ARG; }
+        if (m.type == VMK_MAT_MIX) {
+            if (m.child0 >= sc->n_materials || m.child1 >= sc->n_materials) { ctx->error = "vmk_upload_scene: mix child out of range"; return VMK_ERR_ARG; }
+            uint32_t t0 = sc->materials[m.child0].type, t1 = sc->materials[m.child1].type;
+            if (t0 >= VMK_MAT_PRINCIPLED || t1 >= VMK_MAT_PRINCIPLED) { ctx->error = "vmk_upload_scene: mix children must be single-lobe materials"; return VMK_ERR_UNSUPPORTED; }
+        }
+        if (m.type == VMK_MAT_PRINCIPLED && !sc->luts.sheen_approx && (m.slot[VMK_P_SHEEN_WEIGHT].tex != VMK_INVALID || m.slot[VMK_P_SHEEN_WEIGHT].v[0] != 0.f)) { ctx->error = "vmk_upload_scene: sheen needs the LTC tables"; return VMK_ERR_UNSUPPORTED; }
+    }
+    for (uint32_t i = 0; i < sc->n_textures; ++i) {
+        const vmk_texture &t = sc->textures[i];
+        uint64_t bytes = (uint64_t) t.width * t.height * (t.format == VMK_TEX_RGBA32F ? 16u : 4u);
+        if (t.width == 0 || t.height == 0 || t.format > VMK_TEX_RGBA32F || t.offset % 16 || t.offset + bytes > sc->tex_bytes) { ctx->error = "vmk_upload_scene: texture descriptor out of range"; return VMK_ERR_ARG; }
+    }
+    for (uint32_t i = 0; i < sc->n_lights; ++i) {
+        const vmk_light &l = sc->lights[i];
+        if (!slot_ok(l.color)) { ctx->error = "vmk_upload_scene: light colour references a missing texture"; return VMK_ERR_ARG; }
+        if (l.type == VMK_LIGHT_AREA) {
+            if (l.inst_id >= sc->n_instances || (uint64_t) l.alias_offset + l.alias_count > sc->n_alias || l.alias_count != sc->instances[l.inst_id].tri_count || l.alias_count == 0) { ctx->error = "vmk_upload_scene: area light tables inconsistent"; return VMK_ERR_ARG; }
+        } else if (l.type == VMK_LIGHT_SPHERICAL) {
+            if (l.res_x == 0 || l.res_y == 0 || l.alias_count != l.res_y || (uint64_t) l.alias_offset + l.alias_count > sc->n_alias || (uint64_t) l.cond_offset + (uint64_t) l.res_x * l.res_y > sc->n_alias) { ctx->error = "vmk_upload_scene: environment light tables inconsistent"; return VMK_ERR_ARG; }
+        } else { ctx->error = "vmk_upload_scene: unknown light type"; return VMK_ERR_ARG; }
+    }
+    for (uint32_t i = 0; i < sc->n_alias; ++i) if (sc->alias_idx[i] >= sc->n_alias) { ctx->error = "vmk_upload_scene: alias index out of range"; return VMK_ERR_ARG; }
+    if (sc->env_light != VMK_INVALID && (sc->env_light >= sc->n_lights || sc->lights[sc->env_light].type != VMK_LIGHT_SPHERICAL)) { ctx->error = "vmk_upload_scene: env_light is not a spherical light"; return VMK_ERR_ARG; }
+    if (!sc->luts.pure_reflection || !sc->luts.dielectric || !sc->luts.dielectric_inv || !sc->luts.specular || !sc->luts.coat) { ctx->error = "vmk_upload_scene: albedo tables missing"; return VMK_ERR_ARG; }
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ctx->n_tris = sc->n_tris;
+    HIP_TRY(ctx->tri_pos_in.upload(sc->tri_pos, sc->n_tris, st));
+    HIP_TRY(ctx->tri_attr_in.upload(sc->tri_attr, sc->n_tris, st));
+    HIP_TRY(ctx->instances.upload(sc->instances, sc->n_instances, st));
+    HIP_TRY(ctx->materials.upload(sc->materials, sc->n_materials, st));
+    HIP_TRY(ctx->lights.upload(sc->lights, sc->n_lights, st));
+    HIP_TRY(ctx->textures.upload(sc->textures, sc->n_textures, st));
+    HIP_TRY(ctx->tex_data.upload(sc->tex_data, (size_t) sc->tex_bytes, st));
+    HIP_TRY(ctx->alias_prob.upload(sc->alias_prob, sc->n_alias, st));
+    HIP_TRY(ctx->alias_idx.upload(sc->alias_idx, sc->n_alias, st));
+    HIP_TRY(ctx->alias_func.upload(sc->alias_func, sc->n_alias, st));
+    const uint32_t N = VMK_LUT_RES;
+    const size_t sizes[6] = {(size_t) N * N, (size_t) N * N * N * 2, (size_t) N * N * N * 2, (size_t) N * N * N, (size_t) N * N * N, (size_t) N * N * 4};
+    const float *src[6] = {sc->luts.pure_reflection, sc->luts.dielectric, sc->luts.dielectric_inv, sc->luts.specular, sc->luts.coat, sc->luts.sheen_approx};
+    size_t total = 0; for (int i = 0; i < 6; ++i) total += sizes[i];
+    HIP_TRY(ctx->luts.alloc(total));
+    size_t off[6], o = 0;
+    for (int i = 0; i < 6; ++i) { off[i] = o; if (src[i]) HIP_TRY(hipMemcpyAsync(ctx->luts.p + o, src[i], sizes[i] * 4, hipMemcpyHostToDevice, st)); o += sizes[i]; }
+    DScene &h = ctx->h_scene;
+    h = DScene{};
+    h.instances = ctx->instances.p; h.materials = ctx->materials.p; h.lights = ctx->lights.p; h.textures = ctx->textures.p; h.tex_data = ctx->tex_data.p;
+    h.alias_prob = ctx->alias_prob.p; h.alias_idx = ctx->alias_idx.p; h.alias_func = ctx->alias_func.p; h.srgb_lut = ctx->srgb_lut.p;
+    h.lut_pure_reflection = ctx->luts.p + off[0]; h.lut_dielectric = ctx->luts.p + off[1]; h.lut_dielectric_inv = ctx->luts.p + off[2];
+    h.lut_specular = ctx->luts.p + off[3]; h.lut_coat = ctx->luts.p + off[4]; h.lut_sheen_approx = src[5] ? ctx->luts.p + off[5] : nullptr;
+    h.n_tris = sc->n_tris; h.n_lights = sc->n_lights; h.env_light = sc->env_light;
+    for (int k = 0; k < 3; ++k) { ctx->world_min[k] = sc->world_min[k]; ctx->world_max[k] = sc->world_max[k]; }
+    HIP_TRY(hipStreamSynchronize(st));
+    ctx->scene_ready = true; ctx->accel_ready = false;
+    return VMK_OK;
+}
+
+int vmk_build_accel(vmk_ctx *ctx) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!ctx->scene_ready) { ctx->error = "vmk_build_accel: no scene uploaded"; return VMK_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t n = ctx->n_tris;
+    const int nb = (int) ((n + 255) / 256);
+    DevBuf<uint64_t> keys, keys_sorted;
+    DevBuf<int2> children, ranges;
+    DevBuf<int> parent_internal, parent_leaf, flags, depth;
+    DevBuf<float> leaf_box, node_box;
+    DevBuf<uint32_t> n_leaves;
+    DevBuf<uint8_t> temp;
+    auto cleanup = [&]() { keys.release(); keys_sorted.release(); children.release(); ranges.release(); parent_internal.release(); parent_leaf.release(); flags.release(); depth.release(); leaf_box.release(); node_box.release(); n_leaves.release(); temp.release(); };
+#define BUILD_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return VMK_ERR_HIP; } } while (0)
+    BUILD_TRY(keys.alloc(n)); BUILD_TRY(keys_sorted.alloc(n));
+    BUILD_TRY(ctx->tri_pos.alloc(n)); BUILD_TRY(ctx->tri_attr.alloc(n)); BUILD_TRY(ctx->tri_lookup.alloc(n));
+    size_t n_int = n > 1 ? n - 1 : 1;
+    BUILD_TRY(children.alloc(n_int)); BUILD_TRY(ranges.alloc(n_int)); BUILD_TRY(parent_internal.alloc(n_int)); BUILD_TRY(parent_leaf.alloc(n));
+    BUILD_TRY(flags.alloc(n_int)); BUILD_TRY(depth.alloc(1)); BUILD_TRY(leaf_box.alloc((size_t) n * 6)); BUILD_TRY(node_box.alloc(n_int * 6)); BUILD_TRY(n_leaves.alloc(1));
+    BUILD_TRY(ctx->nodes.alloc(n_int));
+    BUILD_TRY(hipMemsetAsync(flags.p, 0, n_int * sizeof(int), st));
+    BUILD_TRY(hipMemsetAsync(depth.p, 0, sizeof(int), st));
+    BUILD_TRY(hipMemsetAsync(n_leaves.p, 0, sizeof(uint32_t), st));
+    BUILD_TRY(hipMemsetAsync(ctx->nodes.p, 0, n_int * sizeof(BvhNode), st));
+    BUILD_TRY(hipEventRecord(ctx->ev0, st));
+    float ext[3];
+    for (int k = 0; k < 3; ++k) { ext[k] = ctx->world_max[k] - ctx->world_min[k]; ext[k] = ext[k] > 0.f ? 1.f / ext[k] : 0.f; }
+    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, ctx->tri_pos_in.p, n, make_float3(ctx->world_min[0], ctx->world_min[1], ctx->world_min[2]), make_float3(ext[0], ext[1], ext[2]), keys.p);
+    size_t temp_bytes = 0;
+    BUILD_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys.p, keys_sorted.p, (int) n, 0, 64, st));
+    BUILD_TRY(temp.alloc(temp_bytes ? temp_bytes : 16));
+    BUILD_TRY(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys.p, keys_sorted.p, (int) n, 0, 64, st));
+    hipLaunchKernelGGL(k_reorder, dim3(nb), dim3(256), 0, st, keys_sorted.p, n, ctx->tri_pos_in.p, ctx->tri_attr_in.p, ctx->tri_pos.p, ctx->tri_attr.p, ctx->tri_lookup.p);
+    if (n > 1) hipLaunchKernelGGL(k_karras, dim3(nb), dim3(256), 0, st, keys_sorted.p, (int) n, children.p, ranges.p, parent_internal.p, parent_leaf.p);
+    hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, ctx->tri_pos.p, (int) n, children.p, parent_internal.p, parent_leaf.p, leaf_box.p, node_box.p, flags.p);
+    if (n > 1) {
+        hipLaunchKernelGGL(k_depth, dim3(nb), dim3(256), 0, st, (int) n, parent_internal.p, parent_leaf.p, ranges.p, depth.p);
+        hipLaunchKernelGGL(k_emit, dim3(nb), dim3(256), 0, st, (int) n, children.p, ranges.p, leaf_box.p, node_box.p, ctx->nodes.p, n_leaves.p);
+    }
+    BUILD_TRY(hipEventRecord(ctx->ev1, st));
+    BUILD_TRY(hipGetLastError());
+    int h_depth = 0; uint32_t h_leaves = 0;
+    BUILD_TRY(hipMemcpyAsync(&h_depth, depth.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    BUILD_TRY(hipMemcpyAsync(&h_leaves, n_leaves.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    BUILD_TRY(hipStreamSynchronize(st));
+    float ms = 0.f; (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    cleanup();
+#undef BUILD_TRY
+    if (h_depth + 2 > kStackDepth) { ctx->error = "vmk_build_accel: LBVH depth " + std::to_string(h_depth) + " exceeds the LDS traversal stack (" + std::to_string(kStackDepth) + ")"; return VMK_ERR_UNSUPPORTED; }
+    DScene &h = ctx->h_scene;
+    h.tri_pos = ctx->tri_pos.p; h.tri_attr = ctx->tri_attr.p; h.tri_lookup = ctx->tri_lookup.p; h.nodes = ctx->nodes.p;
+    h.root = n <= (uint32_t) kMaxLeafTris ? (int32_t) ~((uint32_t) 0 | ((n - 1u) << 28)) : 0;
+    HIP_TRY(ctx->d_scene.upload(&h, 1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ctx->tri_pos_in.release(); ctx->tri_attr_in.release();
+    ctx->scene_ready = false; // host copies consumed; a new upload is needed before rebuilding
+    ctx->accel = {(uint32_t) (n > 1 ? n - 1 : 0), n <= (uint32_t) kMaxLeafTris ? 1u : h_leaves, (uint32_t) sizeof(BvhNode), (uint32_t) sizeof(vmk_tri_pos), ms};
+    ctx->accel_ready = true;
+    return VMK_OK;
+}
+
+int vmk_accel_info_get(vmk_ctx *ctx, vmk_accel_info *out) {
+    if (!ctx || !out) return VMK_ERR_ARG;
+    if (!ctx->accel_ready) { ctx->error = "vmk_accel_info_get: accel not built"; return VMK_ERR_STATE; }
+    *out = ctx->accel;
+    return VMK_OK;
+}
+
+int vmk_set_render_params(vmk_ctx *ctx, const vmk_render_params *p) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!p || p->width == 0 || p->height == 0 || (uint64_t) p->width * p->height > (1ull << 30)) { ctx->error = "vmk_set_render_params: bad resolution"; return VMK_ERR_ARG; }
+    if (p->filter_type > VMK_FILTER_TABLE || p->mis_mode > 2) { ctx->error = "vmk_set_render_params: bad filter / mis mode"; return VMK_ERR_ARG; }
+    if (p->filter_type == VMK_FILTER_TABLE) {
+        for (uint32_t i = 0; i < VMK_FILTER_TABLE_SIZE; ++i) if (p->filter_marginal_alias[i] >= VMK_FILTER_TABLE_SIZE) { ctx->error = "vmk_set_render_params: filter alias out of range"; return VMK_ERR_ARG; }
+        for (uint32_t i = 0; i < VMK_FILTER_TABLE_SIZE * VMK_FILTER_TABLE_SIZE; ++i) if (p->filter_cond_alias[i] >= VMK_FILTER_TABLE_SIZE) { ctx->error = "vmk_set_render_params: filter alias out of range"; return VMK_ERR_ARG; }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    bool res_changed = !ctx->params_ready || ctx->params.width != p->width || ctx->params.height != p->height;
+    ctx->params = *p;
+    HIP_TRY(ctx->d_params.upload(&ctx->params, 1, ctx->stream));
+    if (res_changed) {
+        size_t n = (size_t) p->width * p->height;
+        if (ctx->fb == ctx->own_fb.p) ctx->fb = nullptr;
+        HIP_TRY(ctx->own_fb.alloc(n));
+        HIP_TRY(ctx->tm_out.alloc(n));
+        HIP_TRY(hipMemsetAsync(ctx->own_fb.p, 0, n * sizeof(float4), ctx->stream));
+        ctx->fb = ctx->own_fb.p;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->params_ready = true;
+    return VMK_OK;
+}
+
+int vmk_set_framebuffer(vmk_ctx *ctx, void *fb_device) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!ctx->params_ready) { ctx->error = "vmk_set_framebuffer: set render params first"; return VMK_ERR_STATE; }
+    ctx->fb = fb_device ? (float4 *) fb_device : ctx->own_fb.p;
+    return VMK_OK;
+}
+
+int vmk_reset_accum(vmk_ctx *ctx) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!ctx->params_ready || !ctx->fb) { ctx->error = "vmk_reset_accum: no framebuffer"; return VMK_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->fb, 0, (size_t) ctx->params.width * ctx->params.height * sizeof(float4), ctx->stream));
+    return VMK_OK;
+}
+
+int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, const vmk_tiles *tiles, float *kernel_ms) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!ctx->accel_ready || !ctx->params_ready || !ctx->fb) { ctx->error = "vmk_render_batch: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    if (frame_count == 0) return VMK_OK;
+    RenderArgs A{};
+    A.scene = ctx->d_scene.p; A.params = ctx->d_params.p; A.accum = ctx->fb; A.queue = ctx->queue.p; A.counters = ctx->counters.p;
+    A.frame_begin = frame_begin; A.frame_count = frame_count;
+    uint32_t ts = kDefaultTile, rank = 0, world = 1;
+    if (tiles && tiles->tile_size) {
+        ts = tiles->tile_size; rank = tiles->rank; world = tiles->world ? tiles->world : 1;
+        if ((ts & (ts - 1)) || ts > 1024 || rank >= world) { ctx->error = "vmk_render_batch: tile_size must be a power of two <= 1024 and rank < world"; return VMK_ERR_ARG; }
+    }
+    uint32_t shift = 0; while ((1u << shift) < ts) ++shift;
+    A.tile_size = ts; A.tile_shift = shift;
+    A.tiles_x = (ctx->params.width + ts - 1) / ts; A.tiles_y = (ctx->params.height + ts - 1) / ts;
+    uint32_t n_tiles = A.tiles_x * A.tiles_y;
+    uint32_t owned = n_tiles > rank ? (n_tiles - rank + world - 1) / world : 0;
+    A.rank = rank; A.world = world;
+    uint64_t n_work = (uint64_t) owned * ts * ts;
+    if (n_work > 0xffffffffull) { ctx->error = "vmk_render_batch: too many work items"; return VMK_ERR_ARG; }
+    A.n_work = (uint32_t) n_work;
+    if (A.n_work == 0) { if (kernel_ms) *kernel_ms = 0.f; return VMK_OK; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, kBlock, 0));
+    if (per_cu < 1) per_cu = 1;
+    uint32_t grid = (uint32_t) std::min<uint64_t>((n_work + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * (uint64_t) per_cu);
+    HIP_TRY(hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream));
+    if (kernel_ms) HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_render, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    if (kernel_ms) {
+        HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(ctx->ev1));
+        HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    }
+    return VMK_OK;
+}
+
+int vmk_synchronize(vmk_ctx *ctx) {
+    if (!ctx) return VMK_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VMK_OK;
+}
+
+int vmk_download_accum(vmk_ctx *ctx, float *out_rgba) {
+    if (!ctx || !out_rgba) return VMK_ERR_ARG;
+    if (!ctx->params_ready || !ctx->fb) { ctx->error = "vmk_download_accum: no framebuffer"; return VMK_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(out_rgba, ctx->fb, (size_t) ctx->params.width * ctx->params.height * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VMK_OK;
+}
+
+int vmk_tonemap(vmk_ctx *ctx, int final_picture, float *out_rgba) {
+    if (!ctx || !out_rgba) return VMK_ERR_ARG;
+    if (!ctx->params_ready || !ctx->fb) { ctx->error = "vmk_tonemap: no framebuffer"; return VMK_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t n = ctx->params.width * ctx->params.height;
+    hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->fb, ctx->tm_out.p, n, ctx->params.exposure, ctx->params.tone_mapper, final_picture);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rgba, ctx->tm_out.p, (size_t) n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VMK_OK;
+}
+
+int vmk_get_counters(vmk_ctx *ctx, vmk_counters *out) {
+    if (!ctx || !out) return VMK_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->closest_rays = h[0]; out->shadow_rays = h[1]; out->nodes_visited = h[2]; out->tris_tested = h[3]; out->paths = h[4]; out->surface_hits = h[5]; out->tex_fetches = h[6];
+    return VMK_OK;
+}
+int vmk_reset_counters(vmk_ctx *ctx) {
+    if (!ctx) return VMK_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    return VMK_OK;
+}
+
+int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *dir_xyz, const float *tmax, int any_hit, uint32_t *hit_out, float *kernel_ms, uint32_t repeats) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!n || !org_xyz || !dir_xyz || !tmax || !hit_out) { ctx->error = "vmk_trace_rays: bad argument"; return VMK_ERR_ARG; }
+    if (!ctx->accel_ready) { ctx->error = "vmk_trace_rays: accel not built"; return VMK_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<float> o, d, t; DevBuf<uint32_t> h;
+    auto cleanup = [&]() { o.release(); d.release(); t.release(); h.release(); };
+    // host arrays are AoS (n x 3); the kernel reads SoA component planes
+    std::vector<float> so((size_t) n * 3), sd((size_t) n * 3);
+    for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { so[(size_t) k * n + i] = org_xyz[(size_t) i * 3 + k]; sd[(size_t) k * n + i] = dir_xyz[(size_t) i * 3 + k]; }
+    hipError_t e;
+    if ((e = o.upload(so.data(), so.size(), ctx->stream)) != hipSuccess || (e = d.upload(sd.data(), sd.size(), ctx->stream)) != hipSuccess ||
+        (e = t.upload(tmax, n, ctx->stream)) != hipSuccess || (e = h.alloc((size_t) n * 4)) != hipSuccess) { ctx->error = std::string("vmk_trace_rays: ") + hipGetErrorString(e); cleanup(); return VMK_ERR_HIP; }
+    uint32_t grid = (uint32_t) std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * 8);
+    if (repeats == 0) repeats = 1;
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipEventRecord(ctx->ev0, ctx->stream);
+    for (uint32_t r = 0; r < repeats; ++r) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p);
+    (void) hipEventRecord(ctx->ev1, ctx->stream);
+    e = hipMemcpyAsync(hit_out, h.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0.f; (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    if (kernel_ms) *kernel_ms = ms / (float) repeats;
+    cleanup();
+    if (e != hipSuccess) { ctx->error = std::string("vmk_trace_rays: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    return VMK_OK;
+}
+
+int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!n || !in || !out || !in_stride || !out_stride || kind > 6) { ctx->error = "vmk_test_eval: bad argument"; return VMK_ERR_ARG; }
+    static const uint32_t min_in[7] = {4, 2, 2, 8, 12, 3, 3}, min_out[7] = {8, 6, 8, 8, 13, 6, 67};
+    if (in_stride < min_in[kind] || out_stride < min_out[kind]) { ctx->error = "vmk_test_eval: stride too small for this kind"; return VMK_ERR_ARG; }
+    if (kind == 4 && !ctx->accel_ready) { ctx->error = "vmk_test_eval: kind 4 needs an uploaded scene + accel"; return VMK_ERR_STATE; }
+    if (kind == 6 && (!ctx->accel_ready || !ctx->params_ready)) { ctx->error = "vmk_test_eval: kind 6 needs scene, accel and render params"; return VMK_ERR_STATE; }
+    if (kind == 5 && !ctx->params_ready) { ctx->error = "vmk_test_eval: kind 5 needs render params"; return VMK_ERR_STATE; }
+    if (kind == 4) { // material ids are validated here: the kernel indexes materials[] with them
+        uint32_t n_mat = (uint32_t) ctx->materials.n;
+        for (uint32_t i = 0; i < n; ++i) { uint32_t id; std::memcpy(&id, in + (size_t) i * in_stride, 4); if (id >= n_mat) { ctx->error = "vmk_test_eval: material id out of range"; return VMK_ERR_ARG; } }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<float> di, dout;
+    hipError_t e = di.upload(in, (size_t) n * in_stride, ctx->stream);
+    if (e == hipSuccess) e = dout.alloc((size_t) n * out_stride);
+    if (e == hipSuccess) e = hipMemsetAsync(dout.p, 0, (size_t) n * out_stride * 4, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_test, dim3((n + 63) / 64), dim3(64), kStackDepth * kBlock * sizeof(uint32_t), ctx->stream, ctx->d_scene.p, ctx->d_params.p, kind, n, di.p, in_stride, dout.p, out_stride);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, (size_t) n * out_stride * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    di.release(); dout.release();
+    if (e != hipSuccess) { ctx->error = std::string("vmk_test_eval: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    return VMK_OK;
+}
+
+}// extern "C"
