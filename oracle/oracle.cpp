@@ -1440,6 +1440,13 @@ int orc_test_eval(void *h, const vmk_render_params *p, uint32_t kind, uint32_t n
                 o[64] = L.x; o[65] = L.y; o[66] = L.z;
                 break;
             }
+            case 50: { // oracle-only: refract (optics.h:28-39; src/tests/test_bxdf.cpp:28-40 vector), Fresnel helpers
+                float3 wt; bool valid = refract(make_float3(a[0], a[1], a[2]), make_float3(a[3], a[4], a[5]), a[6], &wt);
+                float c = abs_(dot(make_float3(a[0], a[1], a[2]), make_float3(a[3], a[4], a[5])));
+                o[0] = valid ? 1.f : 0.f; o[1] = wt.x; o[2] = wt.y; o[3] = wt.z; o[4] = fresnel_dielectric(c, a[6]); o[5] = schlick_weight(c); o[6] = schlick_F0_from_ior(a[6]);
+                break;
+            }
+            case 51: { o[0] = u2f(tea(f2u(a[0]), f2u(a[1]))); break; }
             default: return -1;
         }
     }

@@ -1,0 +1,129 @@
+"""Host logic (no GPU): Vision JSON front-end, per-type defaults, mesh/lights/camera encoding, error behaviour."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from vision_amd import _abi
+from vision_amd.host import HostScene, HostError
+
+
+def _write(tmp_path, name, obj_or_text):
+    p = os.path.join(tmp_path, name)
+    open(p, "w").write(obj_or_text if isinstance(obj_or_text, str) else json.dumps(obj_or_text))
+    return p
+
+
+def _cbox():
+    text = open(os.path.join(ROOT, "scenes", "cbox", "cbox_matte.json")).read()
+    return json.loads("\n".join(l for l in text.split("\n") if not l.startswith("//")))
+
+
+def test_cbox_tables(built):
+    hs = HostScene(os.path.join(ROOT, "scenes", "cbox", "cbox_matte.json"))
+    s = hs.scene
+    assert (s.n_tris, s.n_instances, s.n_materials, s.n_lights) == (36, 8, 8, 1)  # cbox 36 triangles
+    assert s.env_light == _abi.INVALID
+    l = s.lights[0]
+    assert l.type == 0 and l.inst_id == 7 and l.two_sided == 0
+    # Light::initialize_slots (light.cpp:19-24): (17,12,4) normalised by its max, factor folded into scale
+    assert abs(l.scale - 17.0) < 1e-6 and np.allclose(list(l.color.v), [1.0, 12 / 17, 4 / 17])
+    assert l.alias_count == 2 and abs(sum(s.alias_func[l.alias_offset + i] for i in range(2)) - 0.47 * 0.38) < 1e-5
+    p = hs.params
+    assert (p.width, p.height, p.max_depth, p.min_depth, p.filter_type) == (1024, 1024, 16, 0, 1)
+    assert p.tone_mapper == 1 and abs(p.filter_radius[0] - 0.5) < 1e-7
+    assert "integrator/pt" in hs.description and "sensor/thin_lens" in hs.description and "light/area" in hs.description
+
+
+def test_camera_looks_at_target(built):
+    """look_at -> yaw/pitch -> c2w (sensor.cpp:73-78,153-162): the centre pixel's ray passes through target_pos."""
+    from oracle import oracle_py
+    hs = HostScene(os.path.join(ROOT, "scenes", "cbox", "cbox_matte.json"), width=65, height=65)
+    p = hs.params_copy()
+    p.filter_type = 0; p.filter_radius[0] = p.filter_radius[1] = 0.0  # box filter of zero width: exact pixel centre
+    px = np.array([[32, 32, 0]], np.uint32).view(np.float32)
+    ray = oracle_py.test_eval_noscene(5, px, 6, params=p)[0]
+    assert np.allclose(ray[:3], [0, 1, 6.8], atol=1e-5)
+    assert np.allclose(ray[3:], [0, 0, -1], atol=1e-5)
+    corner = oracle_py.test_eval_noscene(5, np.array([[0, 0, 0]], np.uint32).view(np.float32), 6, params=p)[0]
+    t = np.tan(np.radians(19.5) / 2) * (1 - 1 / 65)
+    d = corner[3:] / -corner[5]
+    assert np.allclose(d[:2], [-t, t], atol=1e-4)  # raster (0,0) is the top-left: -x, +y
+
+
+def test_classroom_tables(built):
+    hs = HostScene(os.path.join(ROOT, "scenes", "classroom", "vision_scene.json"))
+    s = hs.scene
+    assert (s.n_tris, s.n_instances, s.n_materials, s.n_lights) == (103832, 79, 45, 1)
+    assert s.env_light == 0 and s.lights[0].type == 1 and s.lights[0].res_x == 2048 and s.lights[0].res_y == 1024
+    types = [s.materials[i].type for i in range(s.n_materials)]
+    assert (types.count(0), types.count(4), types.count(2), types.count(3)) == (36, 5, 3, 1)  # App. C
+    assert (hs.params.width, hs.params.height, hs.params.max_depth, hs.params.min_depth) == (1280, 720, 16, 5)
+    assert "procedural_sky" in hs.description and "medium/ignored" in hs.description
+    # metal/Al: (eta,k) at the three sRGB peak wavelengths (metal.cpp:104-129)
+    al = [s.materials[i] for i in range(s.n_materials) if s.materials[i].type == 2][0]
+    assert np.allclose(list(al.slot[0].v), [1.2203065, 0.919433, 0.6082539], atol=1e-5)
+    assert not (al.flags & 1) and abs(al.slot[2].v[0] - 0.1) < 1e-7  # remapping_roughness false, roughness [0.1,0.1] -> x
+    hs2 = HostScene(os.path.join(ROOT, "scenes", "classroom", "vision_scene.json"), width=1920, height=1080)
+    assert (hs2.params.width, hs2.params.height) == (1920, 1080)
+
+
+def test_alias_tables_are_consistent(built):
+    """AliasTable::build (alias.h:86-122): reconstructing the distribution from (prob, alias) gives back func/sum."""
+    hs = HostScene(os.path.join(ROOT, "scenes", "classroom", "vision_scene.json"))
+    s = hs.scene
+    l = s.lights[0]
+    n = l.alias_count
+    prob = np.array([s.alias_prob[l.alias_offset + i] for i in range(n)])
+    alias = np.array([s.alias_idx[l.alias_offset + i] for i in range(n)])
+    func = np.array([s.alias_func[l.alias_offset + i] for i in range(n)])
+    pmf = np.zeros(n)
+    np.add.at(pmf, np.arange(n), prob / n)
+    np.add.at(pmf, alias, (1 - prob) / n)
+    assert np.allclose(pmf, func / func.sum(), atol=2e-6)
+    assert abs(l.alias_integral - func.sum() / n) < 1e-6 * max(1.0, func.sum() / n)
+
+
+def test_json_comments_and_defaults(built, tmp_path):
+    sc = _cbox()
+    del sc["integrator"]["param"]; del sc["camera"]["param"]["filter"]
+    text = "// line comment\n/* block\n comment */\n" + json.dumps(sc).replace('"shapes"', '/*c*/"shapes"', 1)
+    hs = HostScene(_write(tmp_path, "s.json", text))
+    p = hs.params
+    assert (p.max_depth, p.min_depth, p.rr_threshold, p.mis_mode) == (16, 5, 1.0, 0)  # integrator.cpp:59-66 defaults
+    assert p.filter_type == 2 and abs(p.filter_radius[0] - 0.5) < 1e-7                # FilterDesc default gaussian, r 0.5
+    assert p.env_separate == 0 and abs(p.env_prob - 0.5) < 1e-7 and p.ray_offset_factor == 1.0
+
+
+@pytest.mark.parametrize("mutate, needle", [
+    (lambda s: s["materials"].append({"type": "subsurface", "name": "x", "param": {}}), "material type 'subsurface'"),
+    (lambda s: s["integrator"].update(type="rt"), "integrator/rt"),
+    (lambda s: s["spectrum"].update(type="hero"), "spectrum/hero"),
+    (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "point", "param": {}}), "light/point"),
+    (lambda s: s["shapes"].append({"type": "sphere", "name": "s", "param": {}}), "shape/sphere"),
+    (lambda s: s["shapes"][-1]["param"].pop("emission"), "no light"),
+])
+def test_out_of_scope_features_fail_loudly(built, tmp_path, mutate, needle):
+    """Error behaviour: anything outside the hot-path scope is rejected with a message (the reference OC_ERRORs)."""
+    sc = _cbox()
+    mutate(sc)
+    with pytest.raises(HostError) as e:
+        HostScene(_write(tmp_path, "bad.json", sc))
+    assert needle in str(e.value)
+
+
+def test_obj_loader_fan_triangulation_and_flip_uv(built, tmp_path):
+    obj = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 0.25\nvt 0 1\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"
+    _write(tmp_path, "q.obj", obj)
+    sc = _cbox()
+    sc["shapes"].append({"type": "model", "name": "m", "param": {"fn": "q.obj", "material": "Floor"}})
+    hs = HostScene(_write(tmp_path, "s.json", sc))
+    s = hs.scene
+    assert s.n_tris == 38
+    t0, t1 = s.tri_pos[36], s.tri_pos[37]   # quad -> (0,1,2) and (0,2,3): assimp_parser.cpp:284-295
+    assert list(t0.p2) == [1, 1, 0] and list(t1.p1) == [1, 1, 0] and list(t1.p2) == [0, 1, 0]
+    assert abs(s.tri_attr[36].uv2[1] - 0.75) < 1e-7   # flip_uv default true: v -> 1 - v (model.cpp:30-34)
+    assert list(s.tri_attr[36].n0) == [0, 0, 1]

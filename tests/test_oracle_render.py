@@ -1,0 +1,82 @@
+"""Oracle render regression + multi-rank tile sharding on CPU (gloo, world_size 2) — no GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from vision_amd import _abi
+from vision_amd.host import HostScene
+from oracle import oracle_py
+
+CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materials", "scenes/cbox/cbox_materials.json", 32, 32, 4),
+         ("classroom", "scenes/classroom/vision_scene.json", 48, 27, 2)]
+
+
+@pytest.mark.parametrize("name, path, w, h, spp", CASES)
+def test_oracle_matches_committed_golden(built, name, path, w, h, spp):
+    hs = HostScene(os.path.join(ROOT, path), width=w, height=h)
+    img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_{w}x{h}x{spp}.npy"))
+    assert np.array_equal(img.view(np.uint32), gold.view(np.uint32))  # deterministic: bit-exact across threads/runs
+    assert np.isfinite(img).all() and cnt["paths"] == w * h * spp
+    assert cnt["shadow_rays"] == cnt["surface_hits"]  # one shadow ray per shaded vertex (integrator.cpp:241-243)
+
+
+def test_batch_split_and_tile_sharding_are_exact(built):
+    """Frames accumulate by the running-mean recurrence, so 8 frames == 5 + 3 frames; tiles are disjoint, so the
+    sum over ranks equals the single-rank image bit for bit (x + 0 is exact) — SURVEY.md §8e."""
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_materials.json"), width=40, height=24)
+    osc = oracle_py.OracleScene(hs)
+    p = hs.params_copy()
+    full, _ = osc.render(p, 0, 8)
+    part, _ = osc.render(p, 0, 5)
+    part, _ = osc.render(p, 5, 3, accum=part)
+    assert np.array_equal(full.view(np.uint32), part.view(np.uint32))
+    total = np.zeros_like(full)
+    owned = np.zeros(full.shape[:2], np.int32)
+    for rank in range(3):
+        img, _ = osc.render(p, 0, 8, tiles=_abi.Tiles(8, rank, 3))
+        owned += (img[..., 3] != 0)
+        total += img
+    assert (owned == 1).all()
+    assert np.array_equal(total.view(np.uint32), full.view(np.uint32))
+
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VMK_ROOT"])
+from vision_amd import _abi
+from vision_amd.host import HostScene
+from oracle import oracle_py
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+hs = HostScene(os.path.join(os.environ["VMK_ROOT"], "scenes/cbox/cbox_matte.json"), width=48, height=32)
+osc = oracle_py.OracleScene(hs)
+p = hs.params_copy()
+img, _ = osc.render(p, 0, 4, tiles=_abi.Tiles(16, rank, world), threads=2)
+t = torch.from_numpy(img)
+dist.all_reduce(t, op=dist.ReduceOp.SUM)           # the one collective of the path: framebuffer all-reduce
+if rank == 0:
+    full, _ = osc.render(p, 0, 4, threads=2)
+    assert np.array_equal(t.numpy().view(np.uint32), full.view(np.uint32)), "all-reduced image != single-rank image"
+    print("DIST_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_allreduce_reassembles_the_image(built, tmp_path):
+    """N>1 path on CPU: one process per rank, gloo all-reduce of the float4 framebuffer (RCCL on the GPU box)."""
+    script = os.path.join(tmp_path, "worker.py")
+    open(script, "w").write(WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VMK_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), script],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DIST_OK" in out.stdout
