@@ -192,6 +192,9 @@ inline bool intersect_tri(const vmk_tri_pos &tp, float3 o, float3 d, float *t_ou
 
 struct BVHNode { float bmin[3], bmax[3]; int left, right; int first, count; };
 struct Counters { std::atomic<uint64_t> closest{0}, shadow{0}, nodes{0}, tris{0}, paths{0}, hits{0}, tex{0}; };
+// per-thread tallies (flushed into the scene's atomics when a worker finishes): no shared cache line on the hot path
+struct LocalCounters { uint64_t closest{0}, shadow{0}, nodes{0}, tris{0}, paths{0}, hits{0}, tex{0}; };
+static thread_local LocalCounters tl_cnt;
 
 struct SceneView {
     const vmk_scene *s{};
@@ -199,6 +202,11 @@ struct SceneView {
     std::vector<uint32_t> order; // BVH leaf order -> global triangle index
     Counters cnt;
 
+    void flush_thread_counters() {
+        cnt.closest += tl_cnt.closest; cnt.shadow += tl_cnt.shadow; cnt.nodes += tl_cnt.nodes; cnt.tris += tl_cnt.tris;
+        cnt.paths += tl_cnt.paths; cnt.hits += tl_cnt.hits; cnt.tex += tl_cnt.tex;
+        tl_cnt = LocalCounters{};
+    }
     void build() {
         uint32_t n = s->n_tris;
         order.resize(n);
@@ -257,7 +265,7 @@ struct SceneView {
         return true;
     }
     Hit trace_closest(const Ray &r) {
-        cnt.closest.fetch_add(1, std::memory_order_relaxed);
+        tl_cnt.closest++;
         Hit best; float best_t = r.t_max;
         if (nodes.empty()) return best;
         int stack[128]; int sp = 0; stack[sp++] = 0;
@@ -279,11 +287,11 @@ struct SceneView {
                 }
             } else { stack[sp++] = nd.left; stack[sp++] = nd.right; }
         }
-        cnt.nodes.fetch_add(nn, std::memory_order_relaxed); cnt.tris.fetch_add(nt, std::memory_order_relaxed);
+        tl_cnt.nodes += nn; tl_cnt.tris += nt;
         return best;
     }
     bool trace_occlusion(const Ray &r) {
-        cnt.shadow.fetch_add(1, std::memory_order_relaxed);
+        tl_cnt.shadow++;
         if (nodes.empty()) return false;
         int stack[128]; int sp = 0; stack[sp++] = 0;
         uint64_t nn = 0, nt = 0; bool occ = false;
@@ -299,7 +307,7 @@ struct SceneView {
                 }
             } else { stack[sp++] = nd.left; stack[sp++] = nd.right; }
         }
-        cnt.nodes.fetch_add(nn, std::memory_order_relaxed); cnt.tris.fetch_add(nt, std::memory_order_relaxed);
+        tl_cnt.nodes += nn; tl_cnt.tris += nt;
         return occ;
     }
 };
@@ -1221,7 +1229,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
             bounces -= 1;
             continue;
         }
-        sv.cnt.hits.fetch_add(1, std::memory_order_relaxed);
+        tl_cnt.hits++;
         if (it.has_emission()) { // integrator.cpp:221-231
             LightSampleContext p_ref{ray.o, prev_surface_ng};
             LightEval eval = light_evaluate_hit_wi(lc, p_ref, it);
@@ -1313,7 +1321,7 @@ int orc_render(void *h, const vmk_render_params *p, uint32_t frame_begin, uint32
                     sampler.start(x, y, f, 0); // rt_geom ray generation, frame_buffer.cpp:172-177
                     Ray ray = generate_ray(*p, x, y, sampler);
                     sampler.start(x, y, f, 1); // path_tracing kernel, integrator.cpp:93
-                    sv.cnt.paths.fetch_add(1, std::memory_order_relaxed);
+                    tl_cnt.paths++;
                     float3 L = Li(sv, *p, ray, sampler);
                     float a = 1.f / (float) (f + 1u);
                     float4 val = {L.x, L.y, L.z, 1.f};
@@ -1322,6 +1330,7 @@ int orc_render(void *h, const vmk_render_params *p, uint32_t frame_begin, uint32
                 px[0] = acc.x; px[1] = acc.y; px[2] = acc.z; px[3] = acc.w;
             }
         }
+        sv.flush_thread_counters();
     };
     std::vector<std::thread> pool;
     for (uint32_t i = 1; i < n_threads; ++i) pool.emplace_back(worker);
@@ -1349,6 +1358,7 @@ int orc_trace_rays(void *h, uint32_t n, const float *org, const float *dir, cons
             hit_out[4 * i] = hh.inst; hit_out[4 * i + 1] = hh.prim; hit_out[4 * i + 2] = f2u(hh.bary.x); hit_out[4 * i + 3] = f2u(hh.bary.y);
         }
     }
+    sv.flush_thread_counters();
     return 0;
 }
 

@@ -18,7 +18,8 @@ class BackendError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_PKG, "lib", "libvmk.so")
+    # VMK_LIB: development override used by the tuning scripts to A/B differently compiled builds of the same source
+    return os.environ.get("VMK_LIB") or os.path.join(_PKG, "lib", "libvmk.so")
 
 
 def lib():

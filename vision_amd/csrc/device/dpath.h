@@ -63,30 +63,37 @@ VD float remapping(float a, float low, float high) { return (a - low) / (high - 
 // textures / LUTs: manual bilinear / trilinear on plain HBM arrays (no texture objects).
 // tex.sample semantics: normalised coords, texel centres at (i+0.5)/N, repeat wrap (images), clamp (LUTs).
 // =====================================================================================================
-VD V4 fetch_texel(const DScene &S, const vmk_texture &t, int x, int y) {
-    const uint8_t *base = S.tex_data + t.offset;
-    size_t i = (size_t) y * t.width + (size_t) x;
-    if (t.format == VMK_TEX_RGBA32F) {
+// Textured slots are the rare case (3 of 45 materials in classroom): the bilinear fetch is kept OUT of line so the ~40
+// slot-evaluation sites of the material code stay a compare + 3 moves (code size / VGPR pressure of the megakernel).
+VD V4 fetch_texel(const uint8_t *base, uint32_t format, uint32_t width, const float *srgb_lut, int x, int y) {
+    size_t i = (size_t) y * width + (size_t) x;
+    if (format == VMK_TEX_RGBA32F) {
         float4 p = *reinterpret_cast<const float4 *>(base + i * 16);
         return {p.x, p.y, p.z, p.w};
     }
     uint32_t p = *reinterpret_cast<const uint32_t *>(base + i * 4);
     uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu, a = p >> 24;
-    if (t.format == VMK_TEX_RGBA8_SRGB) return {S.srgb_lut[r], S.srgb_lut[g], S.srgb_lut[b], (float) a * (1.f / 255.f)};
+    if (format == VMK_TEX_RGBA8_SRGB) return {srgb_lut[r], srgb_lut[g], srgb_lut[b], (float) a * (1.f / 255.f)};
     return {(float) r * (1.f / 255.f), (float) g * (1.f / 255.f), (float) b * (1.f / 255.f), (float) a * (1.f / 255.f)};
 }
 VD int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
-VD V4 sample_image(const DScene &S, uint32_t tex_id, V2 uv, DCounters &cnt) {
-    const vmk_texture t = S.textures[tex_id];
-    float x = uv.x * (float) t.width - 0.5f, y = uv.y * (float) t.height - 0.5f;
+__device__ __noinline__ float4 sample_image_ool(const vmk_texture *textures, const uint8_t *tex_data, const float *srgb_lut, uint32_t tex_id, float u, float v) {
+    const vmk_texture t = textures[tex_id];
+    const uint8_t *base = tex_data + t.offset;
+    float x = u * (float) t.width - 0.5f, y = v * (float) t.height - 0.5f;
     float fx0 = floor_(x), fy0 = floor_(y);
     float tx = x - fx0, ty = y - fy0;
     int x0 = wrap_repeat((int) fx0, (int) t.width), y0 = wrap_repeat((int) fy0, (int) t.height);
     int x1 = wrap_repeat((int) fx0 + 1, (int) t.width), y1 = wrap_repeat((int) fy0 + 1, (int) t.height);
-    V4 c00 = fetch_texel(S, t, x0, y0), c10 = fetch_texel(S, t, x1, y0);
-    V4 c01 = fetch_texel(S, t, x0, y1), c11 = fetch_texel(S, t, x1, y1);
+    V4 c00 = fetch_texel(base, t.format, t.width, srgb_lut, x0, y0), c10 = fetch_texel(base, t.format, t.width, srgb_lut, x1, y0);
+    V4 c01 = fetch_texel(base, t.format, t.width, srgb_lut, x0, y1), c11 = fetch_texel(base, t.format, t.width, srgb_lut, x1, y1);
+    V4 r = lerp4(ty, lerp4(tx, c00, c10), lerp4(tx, c01, c11));
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+VD V4 sample_image(const DScene &S, uint32_t tex_id, V2 uv, DCounters &cnt) {
     cnt.tex++;
-    return lerp4(ty, lerp4(tx, c00, c10), lerp4(tx, c01, c11));
+    float4 r = sample_image_ool(S.textures, S.tex_data, S.srgb_lut, tex_id, uv.x, uv.y);
+    return {r.x, r.y, r.z, r.w};
 }
 VD int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
 template<int NC>
@@ -714,7 +721,7 @@ VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i
     const vmk_material *m = mc.m;
     if (m->type == VMK_MAT_MIX) {
         build_simple_lobe(S, S.materials + (i == 0 ? m->child0 : m->child1), it, l, cnt);
-        l.weight = mc.mixw[i]; l.sample_weight = mc.mixw[i];
+        { float mw = i == 0 ? mc.mixw[0] : mc.mixw[1]; l.weight = mw; l.sample_weight = mw; }
         return;
     }
     if (m->type != VMK_MAT_PRINCIPLED) { l = mc.single; return; }
@@ -730,20 +737,18 @@ VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i
         default: l.kind = LB_LAMBERT; l.kr = mc.kr_diff; break;
     }
 }
-// Lobe::evaluate / LobeSet::evaluate_impl (lobe.cpp:53-75,673-688) in world space; all lobes share it.shading
+// Lobe::evaluate / LobeSet::evaluate_impl (lobe.cpp:53-75,673-688) in world space; all lobes share it.shading.
+// A single-lobe material is the n = 1 case of the same loop (its weights are 1, so the products are exact).
 VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Interaction &it, V3 world_wo, V3 world_wi, float *eta, DCounters &cnt) {
     V3 wo = it.shading.to_local(world_wo), wi = it.shading.to_local(world_wi);
-    if (!mc.is_set) {
-        ScatterEval se = eval_local(S, mc.single, wo, wi, eta);
-        se.f *= abs_cos_theta(wi);
-        return se;
-    }
     ScatterEval ret; ret.f = mk3(0.f); ret.pdf = 0.f; ret.flags = flag::Unset;
     bool sh_world = same_hemisphere(world_wo, world_wi, it.shading.z);
+#pragma unroll 1
     for (int i = 0; i < mc.n; ++i) {
         Lobe l; mat_lobe(S, mc, it, i, l, cnt);
         ScatterEval se = eval_local(S, l, wo, wi, eta);
         se.f *= abs_cos_theta(wi);
+        if (!mc.is_set) { ret = se; break; }
         float factor = l.kind == LB_DIELECTRIC ? 1.f : (sh_world ? 1.f : 0.f); // valid_world_factor lobe.cpp:35-38,373-375
         se.f *= l.weight * factor;
         se.pdf *= l.sample_weight * factor;
@@ -753,42 +758,43 @@ VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Inter
     }
     return ret;
 }
-// MaterialEvaluator::evaluate (material.cpp:132-148)
-VD ScatterEval mat_evaluate(const DScene &S, const MatCtx &mc, const Interaction &it, V3 wi, DCounters &cnt) {
-    ScatterEval ret = mat_evaluate_world(S, mc, it, it.wo, wi, nullptr, cnt);
-    bool discard = same_hemisphere(it.wo, wi, it.ng) == ((ret.flags & flag::Transmission) != 0);
-    if (discard) ret.pdf = 0.f;
-    return ret;
-}
-// MaterialEvaluator::sample -> Lobe::sample / LobeSet::sample_wi_impl (material.cpp:166-184, lobe.cpp:111-119,629-658)
-VD BSDFSample mat_sample(const DScene &S, const MatCtx &mc, const Interaction &it, Sampler &sampler, DCounters &cnt) {
-    BSDFSample ret; ret.eta = 1.f;
+// LobeSet::sample_wi_impl (lobe.cpp:629-658) / Lobe::sample_wi_impl: pick the lobe (3 burnt draws for a set), sample locally
+VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sampler &sampler, bool *valid, DCounters &cnt) {
     V3 wo = it.shading.to_local(it.wo);
-    bool valid;
-    V3 wi_local;
+    int strategy = 0;
     if (mc.is_set) {
         float uc = sampler.next_1d();
         (void) sampler.next_2d();
-        int strategy = 0;
         float sum_weights = 0.f;
         for (int i = 0; i < mc.n; ++i) {
             float sw;
-            if (mc.m->type == VMK_MAT_MIX) sw = mc.mixw[i];
+            if (mc.m->type == VMK_MAT_MIX) sw = i == 0 ? mc.mixw[0] : mc.mixw[1];
             else { int k = i + mc.first; sw = k == 0 ? mc.sw[0] : k == 1 ? mc.sw[1] : k == 2 ? mc.sw[2] : k == 3 ? mc.sw[3] : k == 4 ? mc.sw[4] : mc.sw[5]; }
             strategy = uc > sum_weights ? i : strategy;
             sum_weights += sw;
         }
-        Lobe l; mat_lobe(S, mc, it, mc.n == 1 ? 0 : strategy, l, cnt);
-        wi_local = sample_wi_local(l, wo, sampler, &valid);
-    } else {
-        wi_local = sample_wi_local(mc.single, wo, sampler, &valid);
+        if (mc.n == 1) strategy = 0;
     }
-    ret.wi = it.shading.to_world(wi_local);
-    ret.eval = mat_evaluate_world(S, mc, it, it.wo, ret.wi, &ret.eta, cnt);
-    ret.eval.pdf *= valid ? 1.f : 0.f;
-    bool discard = same_hemisphere(it.wo, ret.wi, it.ng) == ((ret.eval.flags & flag::Transmission) != 0);
-    if (discard) ret.eval.pdf = 0.f;
-    return ret;
+    Lobe l; mat_lobe(S, mc, it, strategy, l, cnt);
+    V3 wi_local = sample_wi_local(l, wo, sampler, valid);
+    return it.shading.to_world(wi_local);
+}
+// MaterialEvaluator::evaluate (towards `wi_light`) followed by MaterialEvaluator::sample (material.cpp:132-184,
+// direct_lighting integrator.cpp:20-37): the two evaluations share ONE instance of the lobe code (2-trip loop).
+VD void mat_evaluate_and_sample(const DScene &S, const MatCtx &mc, const Interaction &it, V3 wi_light, Sampler &sampler,
+                                ScatterEval &se_light, BSDFSample &bs, DCounters &cnt) {
+    bs.eta = 1.f; bs.wi = mk3(0.f);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        V3 wi = wi_light;
+        bool valid = true;
+        if (pass == 1) { wi = mat_sample_wi(S, mc, it, sampler, &valid, cnt); bs.wi = wi; }
+        ScatterEval e = mat_evaluate_world(S, mc, it, it.wo, wi, pass == 1 ? &bs.eta : nullptr, cnt);
+        e.pdf *= valid ? 1.f : 0.f;
+        bool discard = same_hemisphere(it.wo, wi, it.ng) == ((e.flags & flag::Transmission) != 0);
+        if (discard) e.pdf = 0.f;
+        if (pass == 0) se_light = e; else bs.eval = e;
+    }
 }
 
 // =====================================================================================================

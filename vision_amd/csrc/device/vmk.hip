@@ -27,6 +27,9 @@ using namespace vmkd;
     } while (0)
 
 constexpr int kBlock = 256;
+#ifndef VMK_WAVES_PER_SIMD
+#define VMK_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane); measured 1:306 2:533 3:652 4:714 Mrays/s on classroom (profiles/r01_tuning.md)
+#endif
 constexpr int kDefaultTile = 32;
 
 // ---------------------------------------------------------------------------------------------------------
@@ -212,8 +215,8 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
     MatCtx mc;
     mat_prepare(S, S.materials + it.mat_id, it, mc, cnt);
     V3 wi = normalize(ls.p_light - it.pos);
-    ScatterEval se = mat_evaluate(S, mc, it, wi, cnt);
-    BSDFSample bs = mat_sample(S, mc, it, sampler, cnt);
+    ScatterEval se; BSDFSample bs;
+    mat_evaluate_and_sample(S, mc, it, wi, sampler, se, bs, cnt);
     if (dbg) { dbg[4] = ls.eval.pdf; dbg[5] = se.pdf; dbg[6] = bs.eval.pdf; dbg[7] = occluded ? 1.f : 0.f; }
     bool is_delta_light = ls.eval.pdf < 0.f;
     float weight = mis_mode != 1 ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, se.pdf)) : 1.f;
@@ -261,7 +264,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_render(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     const DScene S = *A.scene;
     const vmk_render_params *P = A.params;
@@ -424,9 +427,9 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             it.mat_id = mat_id; it.light_id = VMK_INVALID; it.prim_id = 0; it.prim_area = 1.f;
             V3 wi = normalize(mk3(a[7], a[8], a[9]));
             MatCtx mc; mat_prepare(S, S.materials + mat_id, it, mc, cnt);
-            ScatterEval se = mat_evaluate(S, mc, it, wi, cnt);
             Sampler smp; smp.start(f2u(a[1]), f2u(a[2]), f2u(a[3]), 1);
-            BSDFSample bs = mat_sample(S, mc, it, smp, cnt);
+            ScatterEval se; BSDFSample bs;
+            mat_evaluate_and_sample(S, mc, it, wi, smp, se, bs, cnt);
             o[0] = se.f.x; o[1] = se.f.y; o[2] = se.f.z; o[3] = se.pdf; o[4] = u2f(se.flags);
             o[5] = bs.wi.x; o[6] = bs.wi.y; o[7] = bs.wi.z; o[8] = bs.eval.f.x; o[9] = bs.eval.f.y; o[10] = bs.eval.f.z; o[11] = bs.eval.pdf; o[12] = bs.eta;
             break;
