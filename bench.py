@@ -148,6 +148,15 @@ def main():
                          "traffic": None, "kernel": "k_render", "avg_kernel_ms": avg_ms,
                          "traversal_GBs": b_trav / a.steps / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0},
         }
+        # HBM traffic of k_render from separate rocprofv3 --pmc passes of this same command (tools/summarize_profiles.py);
+        # only attached when the profiled workload matches this run, otherwise null.
+        pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+        if world == 1 and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("spp_per_step") == spp and (a.width, a.height) == (1920, 1080):
+                out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = f"profiles/{pmc['tag']}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, (2*FETCH+WRITE)*1024 per launch)"
+                out["roofline"]["algorithmic_bytes_per_launch"] = b_all / a.steps
         if world == 1 and not a.no_cpu_baseline:
             from oracle import oracle_py
             osc = oracle_py.OracleScene(pipe.host_scene)

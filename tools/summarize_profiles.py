@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 run of bench.py (gpurun_out/prof/{kt,pmc_fetch,pmc_write,pmc_l2}) into committed summaries under
+profiles/: <tag>_kernel_stats.csv (top rows of --kernel-trace --stats), <tag>_pmc.json (per-launch HBM traffic of
+k_render, MI355X_MICROARCH.md §HBM corrections) and <tag>_summary.md.   usage: summarize_profiles.py <tag> <spp_per_step> [prof_dir]"""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, spp = sys.argv[1], int(sys.argv[2])
+prof = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "prof")
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+def short(n):
+    return n.split("(")[0][-60:]
+
+stats = list(csv.DictReader(open(glob.glob(os.path.join(prof, "kt", "*", "*_kernel_stats.csv"))[0])))
+with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
+    f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+    for r in stats[:12]:
+        f.write(",".join([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
+kr = [r for r in stats if r["Name"].startswith("k_render")][0]
+
+def pmc(name):
+    f = glob.glob(os.path.join(prof, name, "*", "*_counter_collection.csv"))
+    if not f:
+        return {}, {}
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Kernel_Name"].startswith("k_render")]
+    agg = collections.defaultdict(float)
+    for r in rows:
+        agg[r["Counter_Name"]] += float(r["Counter_Value"])
+    n = len({r["Dispatch_Id"] for r in rows})
+    meta = {k: rows[0][k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")} if rows else {}
+    return {k: v / max(n, 1) for k, v in agg.items()}, meta
+
+fetch, meta = pmc("pmc_fetch"); write, _ = pmc("pmc_write"); l2, _ = pmc("pmc_l2")
+fetch_kb, write_kb = fetch.get("FETCH_SIZE", 0.0), write.get("WRITE_SIZE", 0.0)
+# MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced
+# stream (64 B tallied per 128 B request) -> doubled; WRITE_SIZE is exact.  (16-B gathers are "uncalibrated" per the guide:
+# the doubled figure is an upper estimate for the read side.)
+traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+res = {"tag": tag, "kernel": "k_render", "spp_per_step": spp, "avg_kernel_ns": float(kr["AverageNs"]), "calls": int(kr["Calls"]),
+       "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb, "traffic_bytes_per_launch": traffic,
+       "traffic_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024.0,
+       "L2_hit_rate": l2.get("TCC_HIT_sum", 0) / max(l2.get("TCC_HIT_sum", 0) + l2.get("TCC_MISS_sum", 0), 1), "dispatch": meta}
+json.dump(res, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+bench_line = ""
+for l in open(os.path.join(prof, "bench_kt.log")):
+    if l.startswith('{"metric"'):
+        bench_line = l.strip()
+with open(os.path.join(out, f"{tag}_summary.md"), "w") as f:
+    f.write(f"# {tag}: rocprofv3 summary of `python3 bench.py --spp-per-step {spp}` on MI355X\n\n")
+    f.write(f"* `--kernel-trace --stats`: k_render {kr['Calls']} calls, average {float(kr['AverageNs'])/1e6:.3f} ms (min {float(kr['MinNs'])/1e6:.3f}, max {float(kr['MaxNs'])/1e6:.3f}), {kr['Percentage']} % of GPU time — see `{tag}_kernel_stats.csv`.\n")
+    f.write(f"* separate `--pmc` passes (k_render, per launch): FETCH_SIZE {fetch_kb:.4g} KB, WRITE_SIZE {write_kb:.4g} KB, L2 hit rate {res['L2_hit_rate']:.3f}.\n")
+    f.write(f"* HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = {traffic/1e9:.1f} GB (uncorrected {(fetch_kb+write_kb)*1024/1e9:.1f} GB) -> {traffic/float(kr['AverageNs']):.1f} GB/s.\n")
+    f.write(f"* dispatch: {meta}\n\nbench line under the profiler:\n\n```\n{bench_line}\n```\n")
+print(json.dumps(res, indent=1))
