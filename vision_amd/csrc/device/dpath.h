@@ -538,6 +538,27 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
     return wi;
 }
 
+// Out-of-line instances of the two big lobe routines.  Inlined into the 2-pass evaluate/sample loop they cost ~170 live
+// VGPRs (LICM hoists every wo-only term of every lobe kind out of the loop); as real calls the lobe code is compiled
+// once at <= 71 VGPRs and the megakernel fits 128 VGPRs (4 waves/SIMD) with far fewer spills.
+__device__ __noinline__ void eval_local_ool(const DScene *S, const Lobe *l, float wox, float woy, float woz, float wix, float wiy, float wiz,
+                                            float *eta, ScatterEval *out) {
+    *out = eval_local(*S, *l, mk3(wox, woy, woz), mk3(wix, wiy, wiz), eta);
+}
+__device__ __noinline__ void sample_wi_local_ool(const Lobe *l, float wox, float woy, float woz, Sampler *sampler, V3 *wi, bool *valid) {
+    *wi = sample_wi_local(*l, mk3(wox, woy, woz), *sampler, valid);
+}
+VD ScatterEval eval_local_call(const DScene &S, const Lobe &l, V3 wo, V3 wi, float *eta) {
+    ScatterEval se;
+    eval_local_ool(&S, &l, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z, eta, &se);
+    return se;
+}
+VD V3 sample_wi_local_call(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
+    V3 wi;
+    sample_wi_local_ool(&l, wo.x, wo.y, wo.z, &sampler, &wi, valid);
+    return wi;
+}
+
 VD void microfacet_alpha(const DScene &S, const vmk_material *m, int slot_r, int slot_a, V2 uv, float rmin, float *ax, float *ay, DCounters &cnt) {
     float roughness = clamp_(eval_slot1(S, m->slot[slot_r], uv, cnt), rmin, 1.f);
     float anisotropic = clamp_(eval_slot1(S, m->slot[slot_a], uv, cnt), -0.9f, 0.9f);
@@ -621,8 +642,17 @@ struct MatCtx {
     V3 f82_b, f0_spec, f0_trans;
     float sw[6];
 };
+// FULL = the scene contains mix / principled_bsdf materials.  Like the reference, which JIT-compiles only the material
+// types a scene uses, the megakernel exists in two ahead-of-time variants; the single-lobe variant carries no lobe-set
+// state at all (lower VGPR pressure, no lobe loop).
+template<bool FULL>
 VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &it, MatCtx &mc, DCounters &cnt) {
     mc.m = m;
+    if constexpr (!FULL) {
+        mc.n = 1; mc.is_set = false;
+        build_simple_lobe(S, m, it, mc.single, cnt);
+        return;
+    }
     if (m->type == VMK_MAT_MIX) { // mix.cpp:66-71 + LobeSet::create_mix (lobe.cpp:495-508)
         float frac = eval_slot1(S, m->slot[0], it.uv, cnt);
         mc.mixw[0] = 1.f - frac; mc.mixw[1] = frac;
@@ -717,7 +747,9 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
     mc.n = 6 - mc.first;
 }
 // expand lobe `i` (0-based within the material's lobe list)
+template<bool FULL>
 VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i, Lobe &l, DCounters &cnt) {
+    if constexpr (!FULL) { l = mc.single; return; }
     const vmk_material *m = mc.m;
     if (m->type == VMK_MAT_MIX) {
         build_simple_lobe(S, S.materials + (i == 0 ? m->child0 : m->child1), it, l, cnt);
@@ -739,14 +771,20 @@ VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i
 }
 // Lobe::evaluate / LobeSet::evaluate_impl (lobe.cpp:53-75,673-688) in world space; all lobes share it.shading.
 // A single-lobe material is the n = 1 case of the same loop (its weights are 1, so the products are exact).
+template<bool FULL>
 VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Interaction &it, V3 world_wo, V3 world_wi, float *eta, DCounters &cnt) {
     V3 wo = it.shading.to_local(world_wo), wi = it.shading.to_local(world_wi);
+    if constexpr (!FULL) {
+        ScatterEval se = eval_local_call(S, mc.single, wo, wi, eta);
+        se.f *= abs_cos_theta(wi);
+        return se;
+    }
     ScatterEval ret; ret.f = mk3(0.f); ret.pdf = 0.f; ret.flags = flag::Unset;
     bool sh_world = same_hemisphere(world_wo, world_wi, it.shading.z);
 #pragma unroll 1
     for (int i = 0; i < mc.n; ++i) {
-        Lobe l; mat_lobe(S, mc, it, i, l, cnt);
-        ScatterEval se = eval_local(S, l, wo, wi, eta);
+        Lobe l; mat_lobe<FULL>(S, mc, it, i, l, cnt);
+        ScatterEval se = eval_local_call(S, l, wo, wi, eta);
         se.f *= abs_cos_theta(wi);
         if (!mc.is_set) { ret = se; break; }
         float factor = l.kind == LB_DIELECTRIC ? 1.f : (sh_world ? 1.f : 0.f); // valid_world_factor lobe.cpp:35-38,373-375
@@ -759,8 +797,10 @@ VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Inter
     return ret;
 }
 // LobeSet::sample_wi_impl (lobe.cpp:629-658) / Lobe::sample_wi_impl: pick the lobe (3 burnt draws for a set), sample locally
+template<bool FULL>
 VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sampler &sampler, bool *valid, DCounters &cnt) {
     V3 wo = it.shading.to_local(it.wo);
+    if constexpr (!FULL) return it.shading.to_world(sample_wi_local_call(mc.single, wo, sampler, valid));
     int strategy = 0;
     if (mc.is_set) {
         float uc = sampler.next_1d();
@@ -775,12 +815,13 @@ VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sa
         }
         if (mc.n == 1) strategy = 0;
     }
-    Lobe l; mat_lobe(S, mc, it, strategy, l, cnt);
-    V3 wi_local = sample_wi_local(l, wo, sampler, valid);
+    Lobe l; mat_lobe<FULL>(S, mc, it, strategy, l, cnt);
+    V3 wi_local = sample_wi_local_call(l, wo, sampler, valid);
     return it.shading.to_world(wi_local);
 }
 // MaterialEvaluator::evaluate (towards `wi_light`) followed by MaterialEvaluator::sample (material.cpp:132-184,
 // direct_lighting integrator.cpp:20-37): the two evaluations share ONE instance of the lobe code (2-trip loop).
+template<bool FULL>
 VD void mat_evaluate_and_sample(const DScene &S, const MatCtx &mc, const Interaction &it, V3 wi_light, Sampler &sampler,
                                 ScatterEval &se_light, BSDFSample &bs, DCounters &cnt) {
     bs.eta = 1.f; bs.wi = mk3(0.f);
@@ -788,8 +829,8 @@ VD void mat_evaluate_and_sample(const DScene &S, const MatCtx &mc, const Interac
     for (int pass = 0; pass < 2; ++pass) {
         V3 wi = wi_light;
         bool valid = true;
-        if (pass == 1) { wi = mat_sample_wi(S, mc, it, sampler, &valid, cnt); bs.wi = wi; }
-        ScatterEval e = mat_evaluate_world(S, mc, it, it.wo, wi, pass == 1 ? &bs.eta : nullptr, cnt);
+        if (pass == 1) { wi = mat_sample_wi<FULL>(S, mc, it, sampler, &valid, cnt); bs.wi = wi; }
+        ScatterEval e = mat_evaluate_world<FULL>(S, mc, it, it.wo, wi, pass == 1 ? &bs.eta : nullptr, cnt);
         e.pdf *= valid ? 1.f : 0.f;
         bool discard = same_hemisphere(it.wo, wi, it.ng) == ((e.flags & flag::Transmission) != 0);
         if (discard) e.pdf = 0.f;

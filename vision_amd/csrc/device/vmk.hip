@@ -288,6 +288,7 @@ __device__ __forceinline__ void path_begin(PathState &ps) {
     ps.L = mk3(0.f); ps.T = mk3(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
 }
 // returns true when the path ends at this vertex.  `dbg` (tests only): 8 floats per vertex.
+template<bool FULL>
 __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, uint32_t *stack, PathState &ps, Sampler &sampler,
                                             DCounters &cnt, float *dbg) {
     const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
@@ -328,10 +329,10 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
     bool occluded = traverse<true>(S, shadow_ray, stack, kBlock, sh, cnt);
     // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
     MatCtx mc;
-    mat_prepare(S, S.materials + it.mat_id, it, mc, cnt);
+    mat_prepare<FULL>(S, S.materials + it.mat_id, it, mc, cnt);
     V3 wi = normalize(ls.p_light - it.pos);
     ScatterEval se; BSDFSample bs;
-    mat_evaluate_and_sample(S, mc, it, wi, sampler, se, bs, cnt);
+    mat_evaluate_and_sample<FULL>(S, mc, it, wi, sampler, se, bs, cnt);
     if (dbg) { dbg[4] = ls.eval.pdf; dbg[5] = se.pdf; dbg[6] = bs.eval.pdf; dbg[7] = occluded ? 1.f : 0.f; }
     bool is_delta_light = ls.eval.pdf < 0.f;
     float weight = mis_mode != 1 ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, se.pdf)) : 1.f;
@@ -379,6 +380,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+template<bool FULL>
 __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     const DScene S = *A.scene;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
         }
 
         // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
-        bool terminate = path_bounce(S, P, stack, ps, sampler, cnt, nullptr);
+        bool terminate = path_bounce<FULL>(S, P, stack, ps, sampler, cnt, nullptr);
         if (terminate) { // RGBFilm accumulation, frame_buffer.cpp:117-126
             float a = 1.f / (float) (frame + 1u);
             V4 val = {ps.L.x, ps.L.y, ps.L.z, 1.f};
@@ -541,10 +543,10 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             it.uv = {a[10], a[11]};
             it.mat_id = mat_id; it.light_id = VMK_INVALID; it.prim_id = 0; it.prim_area = 1.f;
             V3 wi = normalize(mk3(a[7], a[8], a[9]));
-            MatCtx mc; mat_prepare(S, S.materials + mat_id, it, mc, cnt);
+            MatCtx mc; mat_prepare<true>(S, S.materials + mat_id, it, mc, cnt);
             Sampler smp; smp.start(f2u(a[1]), f2u(a[2]), f2u(a[3]), 1);
             ScatterEval se; BSDFSample bs;
-            mat_evaluate_and_sample(S, mc, it, wi, smp, se, bs, cnt);
+            mat_evaluate_and_sample<true>(S, mc, it, wi, smp, se, bs, cnt);
             o[0] = se.f.x; o[1] = se.f.y; o[2] = se.f.z; o[3] = se.pdf; o[4] = u2f(se.flags);
             o[5] = bs.wi.x; o[6] = bs.wi.y; o[7] = bs.wi.z; o[8] = bs.eval.f.x; o[9] = bs.eval.f.y; o[10] = bs.eval.f.z; o[11] = bs.eval.pdf; o[12] = bs.eta;
             break;
@@ -565,7 +567,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             path_begin(ps);
             for (int v = 0; v < 64; ++v) {
                 float dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                bool end = path_bounce(S, P, s_dyn_stack + threadIdx.x, ps, smp, cnt, dbg);
+                bool end = path_bounce<true>(S, P, s_dyn_stack + threadIdx.x, ps, smp, cnt, dbg);
                 if (v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
                 if (end) break;
             }
@@ -600,6 +602,7 @@ struct vmk_ctx {
     int n_cus{256};
     // scene
     bool scene_ready{false}, accel_ready{false}, params_ready{false};
+    bool full_materials{true}; // scene has mix / principled_bsdf -> lobe-set variant of the megakernel
     uint32_t n_tris{0};
     DevBuf<vmk_tri_pos> tri_pos_in, tri_pos;
     DevBuf<vmk_tri_attr> tri_attr_in, tri_attr;
@@ -716,6 +719,9 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     if (sc->env_light != VMK_INVALID && (sc->env_light >= sc->n_lights || sc->lights[sc->env_light].type != VMK_LIGHT_SPHERICAL)) { ctx->error = "vmk_upload_scene: env_light is not a spherical light"; return VMK_ERR_ARG; }
     if (!sc->luts.pure_reflection || !sc->luts.dielectric || !sc->luts.dielectric_inv || !sc->luts.specular || !sc->luts.coat) { ctx->error = "vmk_upload_scene: albedo tables missing"; return VMK_ERR_ARG; }
 
+    ctx->full_materials = false;
+    for (uint32_t i = 0; i < sc->n_materials; ++i) if (sc->materials[i].type >= VMK_MAT_PRINCIPLED) ctx->full_materials = true;
+    if (const char *v = getenv("VMK_FORCE_FULL")) if (v[0] == '1') ctx->full_materials = true;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     ctx->n_tris = sc->n_tris;
@@ -939,12 +945,13 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     if (A.n_work == 0) { if (kernel_ms) *kernel_ms = 0.f; return VMK_OK; }
     HIP_TRY(hipSetDevice(ctx->device));
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, kBlock, 0));
+    auto kernel = ctx->full_materials ? k_render<true> : k_render<false>;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
     uint32_t grid = (uint32_t) std::min<uint64_t>((n_work + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * (uint64_t) per_cu);
     HIP_TRY(hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_render, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     if (kernel_ms) {
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
