@@ -7,6 +7,10 @@
 
 namespace vmkd {
 
+// Traversal stack: LDS only, stack[level][thread] (stride = block size, so consecutive lanes hit consecutive banks).
+// 40 levels x 4 B = 10 KB per wave -> 16 waves per CU fit in 160 KB.  The depth of a built tree is checked against
+// kStackDepth at build time.  (Measured alternatives on classroom: spilling deep levels to a per-lane private array
+// costs 28 % — 1920 -> 1373 Mrays/s — and 48 LDS levels at 2 blocks/CU cost 41 %.)
 constexpr int kStackDepth = 40;
 
 struct Hit { uint32_t inst, prim, tri; V2 bary; };
@@ -51,12 +55,15 @@ VD bool traverse(const DScene &S, const Ray &r, uint32_t *stack, int stride, Hit
     float best_t = r.t_max;
     hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
     if (S.n_tris == 0) return false;
+    constexpr int32_t kDone = 0x7fffffff;
     int sp = 0;
     int32_t cur = S.root;
     uint32_t nn = 0, nt = 0;
     bool found = false;
-    for (;;) {
-        if (cur >= 0) {
+    // "while-while": all lanes of the wave first descend through internal nodes, then the lanes that reached a leaf test
+    // their triangles together — fewer serialised node/leaf branches per wave (+14 % Mrays/s on classroom).
+    while (cur != kDone) {
+        while (cur >= 0 && cur != kDone) {
             const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
             float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
             ++nn;
@@ -68,15 +75,14 @@ VD bool traverse(const DScene &S, const Ray &r, uint32_t *stack, int stride, Hit
             bool hr = hit_box(rmin, rmax, r.o, inv, best_t, &tr);
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                int32_t near_c = left_first ? left : right, far_c = left_first ? right : left;
-                if (sp < kStackDepth) { stack[sp * stride] = (uint32_t) far_c; ++sp; } // depth is checked at build time
-
-                cur = near_c;
-                continue;
-            }
-            if (hl) { cur = left; continue; }
-            if (hr) { cur = right; continue; }
-        } else {
+                if (sp < kStackDepth) { stack[sp * stride] = (uint32_t) (left_first ? right : left); ++sp; }
+                cur = left_first ? left : right;
+            } else if (hl) cur = left;
+            else if (hr) cur = right;
+            else if (sp > 0) { --sp; cur = (int32_t) stack[sp * stride]; }
+            else cur = kDone;
+        }
+        if (cur != kDone) {
             uint32_t v = ~(uint32_t) cur;
             uint32_t first = v & kLeafFirstMask, count = (v >> 28) + 1u;
             for (uint32_t i = 0; i < count; ++i) {
@@ -91,10 +97,9 @@ VD bool traverse(const DScene &S, const Ray &r, uint32_t *stack, int stride, Hit
                 if (better) { best_t = t; hit.inst = inst; hit.prim = prim; hit.tri = first + i; hit.bary = {u, w}; found = true; }
             }
             if (ANY_HIT && found) break;
+            if (sp > 0) { --sp; cur = (int32_t) stack[sp * stride]; }
+            else cur = kDone;
         }
-        if (sp == 0) break;
-        --sp;
-        cur = (int32_t) stack[sp * stride];
     }
     cnt.nodes += nn; cnt.tris += nt;
     return found;
