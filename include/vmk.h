@@ -242,7 +242,7 @@ const char *vmk_last_error(const vmk_ctx *ctx); /* valid until the next call on 
 uint32_t vmk_abi_version(void);
 
 int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *scene);
-int vmk_build_accel(vmk_ctx *ctx); /* GPU LBVH: Morton codes -> radix sort -> Karras hierarchy -> refit */
+int vmk_build_accel(vmk_ctx *ctx); /* GPU build: Morton codes -> radix sort -> PLOC merge rounds -> 64 B BVH2 nodes */
 int vmk_set_render_params(vmk_ctx *ctx, const vmk_render_params *params);
 
 /* Film. fb == NULL: the ctx owns a width*height float4 accumulation buffer. Otherwise fb is a DEVICE
@@ -268,6 +268,8 @@ void *vmk_stream(vmk_ctx *ctx); /* hipStream_t the ctx launches on */
 typedef struct vmk_accel_info {
     uint32_t n_nodes, n_leaves, node_bytes, tri_bytes;
     float build_ms;
+    uint32_t depth;       /* internal nodes on the longest root-to-leaf path */
+    uint32_t stack_depth; /* entries of the per-lane LDS traversal stack; builds with depth + 2 > stack_depth are rejected */
 } vmk_accel_info;
 int vmk_accel_info_get(vmk_ctx *ctx, vmk_accel_info *out);
 
@@ -279,7 +281,10 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
 
 /* ---- device-side unit entry points used by the parity tests (tests/ only) ------------------------------ */
 /* Evaluate n independent work items of test `kind` on the GPU; in/out are plain float arrays with
- * in_stride/out_stride floats per item (layouts documented in tests/test_device_units.py). */
+ * in_stride/out_stride floats per item (layouts documented in tests/test_gpu_parity.py).
+ * kind 7 is the ray capture that feeds vmk_trace_rays replays: in = {pixel x, pixel y, frame} as u32 bit
+ * patterns, out = {vertex count, then 16 floats per path vertex: closest ray o.xyz d.xyz t_max 1 | shadow
+ * ray o.xyz d.xyz t_max traced} for up to 24 vertices (out_stride >= 385). */
 int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out,
                   uint32_t out_stride);
 

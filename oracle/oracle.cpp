@@ -195,6 +195,10 @@ struct Counters { std::atomic<uint64_t> closest{0}, shadow{0}, nodes{0}, tris{0}
 // per-thread tallies (flushed into the scene's atomics when a worker finishes): no shared cache line on the hot path
 struct LocalCounters { uint64_t closest{0}, shadow{0}, nodes{0}, tris{0}, paths{0}, hits{0}, tex{0}; };
 static thread_local LocalCounters tl_cnt;
+// optional ray capture (orc_dump_rays): every ray the integrator traces is appended as 10 words
+// [o.xyz, d.xyz, t_max, kind (0 closest / 1 occlusion), path id, sequence number within the path]
+struct RayDump { std::vector<uint32_t> words; uint32_t path{0}, seq{0}; };
+static thread_local RayDump *tl_dump = nullptr;
 
 struct SceneView {
     const vmk_scene *s{};
@@ -264,8 +268,15 @@ struct SceneView {
         }
         return true;
     }
+    static void dump_ray(const Ray &r, uint32_t kind) {
+        if (!tl_dump) return;
+        float f[7] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.t_max};
+        for (float x : f) tl_dump->words.push_back(f2u(x));
+        tl_dump->words.push_back(kind); tl_dump->words.push_back(tl_dump->path); tl_dump->words.push_back(tl_dump->seq++);
+    }
     Hit trace_closest(const Ray &r) {
         tl_cnt.closest++;
+        dump_ray(r, 0);
         Hit best; float best_t = r.t_max;
         if (nodes.empty()) return best;
         int stack[128]; int sp = 0; stack[sp++] = 0;
@@ -292,6 +303,7 @@ struct SceneView {
     }
     bool trace_occlusion(const Ray &r) {
         tl_cnt.shadow++;
+        dump_ray(r, 1);
         if (nodes.empty()) return false;
         int stack[128]; int sp = 0; stack[sp++] = 0;
         uint64_t nn = 0, nt = 0; bool occ = false;
@@ -1341,6 +1353,31 @@ int orc_render(void *h, const vmk_render_params *p, uint32_t frame_begin, uint32
         counters->tris_tested = sv.cnt.tris; counters->paths = sv.cnt.paths; counters->surface_hits = sv.cnt.hits; counters->tex_fetches = sv.cnt.tex;
     }
     return 0;
+}
+
+// Ray capture for the traversal-only replay (SURVEY §8d "replay kernel reads ray buffers dumped from C3"): runs frame
+// `frame` of every `stride`-th pixel in x and y single-threaded and returns every ray Li() traced, 10 words each (see
+// RayDump).  out may be null to query the count; returns the number of rays (clamped to max_rays when out is given).
+uint32_t orc_dump_rays(void *h, const vmk_render_params *p, uint32_t frame, uint32_t stride, uint32_t *out, uint32_t max_rays) {
+    SceneView &sv = ((orc_scene_handle *) h)->sv;
+    RayDump dump;
+    tl_dump = &dump;
+    if (stride == 0) stride = 1;
+    for (uint32_t y = 0; y < p->height; y += stride)
+        for (uint32_t x = 0; x < p->width; x += stride) {
+            Sampler sampler;
+            sampler.start(x, y, frame, 0);
+            Ray ray = generate_ray(*p, x, y, sampler);
+            sampler.start(x, y, frame, 1);
+            dump.seq = 0;
+            Li(sv, *p, ray, sampler);
+            dump.path++;
+        }
+    tl_dump = nullptr;
+    tl_cnt = LocalCounters{};
+    uint32_t n = (uint32_t) (dump.words.size() / 10);
+    if (out) { n = std::min(n, max_rays); std::memcpy(out, dump.words.data(), (size_t) n * 40); }
+    return n;
 }
 
 void orc_reset_counters(void *h) {

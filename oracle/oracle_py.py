@@ -42,6 +42,8 @@ def lib():
         L.orc_test_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                     C.c_void_p, C.c_uint32]
         L.orc_integrate_albedo.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+        L.orc_dump_rays.restype = C.c_uint32
+        L.orc_dump_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         _LIB = L
     return _LIB
 
@@ -76,6 +78,16 @@ class OracleScene:
         out = np.zeros((n, 4), np.uint32)
         lib().orc_trace_rays(self._h, n, _ptr(org), _ptr(dirs), _ptr(tmax), int(any_hit), _ptr(out))
         return out
+
+    def dump_rays(self, params, frame=0, stride=1):
+        """Every ray Li() traces for frame `frame` of each stride-th pixel: dict of SoA arrays (org, dir, tmax, kind,
+        path, seq) in path order — the input of the traversal-only replay."""
+        n = lib().orc_dump_rays(self._h, C.byref(params), frame, stride, None, 0)
+        buf = np.zeros((n, 10), np.uint32)
+        lib().orc_dump_rays(self._h, C.byref(params), frame, stride, _ptr(buf), n)
+        f = buf.view(np.float32)
+        return {"org": f[:, 0:3].copy(), "dir": f[:, 3:6].copy(), "tmax": f[:, 6].copy(), "kind": buf[:, 7].copy(),
+                "path": buf[:, 8].copy(), "seq": buf[:, 9].copy()}
 
     def test_eval(self, params, kind, inp, out_stride):
         inp = np.ascontiguousarray(inp, np.float32)

@@ -164,3 +164,30 @@ def test_error_behaviour(backend):
     with pytest.raises(BackendError, match="bad argument"):
         be.test_eval(99, np.zeros((1, 4), np.float32), 8)
     be.close()
+
+
+@pytest.mark.parametrize("scene,w,h", [("scenes/cbox/cbox_materials.json", 40, 40), ("scenes/classroom/vision_scene.json", 64, 36)])
+def test_captured_rays_match_oracle_and_replay(backend, scene, w, h):
+    """The ray capture that feeds the traversal replay (k_test kind 7) returns exactly the rays the oracle's Li()
+    traces — origins, directions and t_max bit for bit — and replaying them through k_trace gives the oracle's hits."""
+    hs, p, osc, _ = _load(backend, scene, w, h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    pix = np.stack([xx.ravel(), yy.ravel()], 1).astype(np.uint32)
+    g = backend.capture_rays(pix, frame=3)
+    o = osc.dump_rays(p, frame=3, stride=1)
+    # oracle order is (path, seq); vertex = closest rays traced so far on the path - 1; GPU order is (vertex, kind, path)
+    first = np.r_[True, o["path"][1:] != o["path"][:-1]]
+    closest_cum = np.cumsum(o["kind"] == 0)
+    base = np.maximum.accumulate(np.where(first, closest_cum - (o["kind"] == 0), 0))
+    vertex = closest_cum - base - 1
+    assert vertex.max() < 24, "capture holds 24 vertices per path"
+    order = np.lexsort((o["path"], o["kind"], vertex))
+    assert g["kind"].shape == o["kind"].shape
+    assert np.array_equal(g["kind"], o["kind"][order])
+    for k in ("org", "dir", "tmax"):
+        assert _bits_equal(g[k], o[k][order]), k
+    for kind in (0, 1):
+        m = g["kind"] == kind
+        hg, _ = backend.trace(g["org"][m], g["dir"][m], g["tmax"][m], any_hit=bool(kind))
+        ho = osc.trace(g["org"][m], g["dir"][m], g["tmax"][m], any_hit=bool(kind))
+        assert np.array_equal(hg, ho)

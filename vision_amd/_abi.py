@@ -85,7 +85,8 @@ class Counters(C.Structure):
 
 
 class AccelInfo(C.Structure):
-    _fields_ = [("n_nodes", u32), ("n_leaves", u32), ("node_bytes", u32), ("tri_bytes", u32), ("build_ms", f32)]
+    _fields_ = [("n_nodes", u32), ("n_leaves", u32), ("node_bytes", u32), ("tri_bytes", u32), ("build_ms", f32),
+                ("depth", u32), ("stack_depth", u32)]
 
 
 class HostOptions(C.Structure):

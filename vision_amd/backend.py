@@ -145,6 +145,20 @@ class Backend:
         self._check(self._L.vmk_test_eval(self._h, kind, inp.shape[0], _ptr(inp), inp.shape[1], _ptr(out), out_stride))
         return out
 
+    def capture_rays(self, pixels_xy, frame=0):
+        """Rays the megakernel traces for `frame` of the given pixels (k_test kind 7), as SoA arrays ordered by
+        (vertex, ray kind, pixel) — i.e. what the lanes of one wave trace together.  Feeds trace() replays."""
+        pix = np.ascontiguousarray(pixels_xy, np.uint32)
+        inp = np.concatenate([pix, np.full((pix.shape[0], 1), frame, np.uint32)], axis=1).view(np.float32)
+        rec = self.test_eval(7, inp, 1 + 16 * 24)
+        nv = rec[:, 0].astype(np.int64)
+        v = rec[:, 1:].reshape(-1, 24, 2, 8)          # [path, vertex, closest/shadow, (o, d, tmax, valid)]
+        v = np.transpose(v, (1, 2, 0, 3))             # [vertex, kind, path, 8]
+        valid = (v[..., 7] == 1.0) & (np.arange(24)[:, None, None] < nv[None, None, :])
+        kind = np.broadcast_to(np.arange(2, dtype=np.uint32)[None, :, None], valid.shape)
+        r = v[valid]
+        return {"org": r[:, 0:3].copy(), "dir": r[:, 3:6].copy(), "tmax": r[:, 6].copy(), "kind": kind[valid].copy()}
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.vmk_destroy(self._h)

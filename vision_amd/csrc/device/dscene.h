@@ -5,12 +5,14 @@
 
 namespace vmkd {
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 // BVH2 node, 64 B = one S_node record: both child AABBs live in the parent so one fetch decides both
-// children.  child >= 0: internal node index.  child < 0: leaf, v = ~child, first triangle = v & 0x0fffffff (index
+// children.  Each slab is a (min, max) pair — the operand shape of the packed-fp32 slab test in dbvh.h.  child >= 0: internal node index.  child < 0: leaf, v = ~child, first triangle = v & 0x0fffffff (index
 // into the Morton-ordered triangle arrays), count = (v >> 28) + 1.
 struct alignas(16) BvhNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
+    float lx[2], ly[2], lz[2]; // left child:  (min, max) per axis
+    float rx[2], ry[2], rz[2]; // right child
     int32_t left, right;
     uint32_t pad0, pad1;
 };

@@ -158,7 +158,8 @@ __global__ void k_emit(int n, const int2 *children, const int2 *ranges, const fl
     const float *lb = c.x >= 0 ? node_box + (size_t) c.x * 6 : leaf_box + (size_t) (~c.x) * 6;
     const float *rb = c.y >= 0 ? node_box + (size_t) c.y * 6 : leaf_box + (size_t) (~c.y) * 6;
     BvhNode nd;
-    for (int a = 0; a < 3; ++a) { nd.lmin[a] = lb[a]; nd.lmax[a] = lb[3 + a]; nd.rmin[a] = rb[a]; nd.rmax[a] = rb[3 + a]; }
+    nd.lx[0] = lb[0]; nd.lx[1] = lb[3]; nd.ly[0] = lb[1]; nd.ly[1] = lb[4]; nd.lz[0] = lb[2]; nd.lz[1] = lb[5];
+    nd.rx[0] = rb[0]; nd.rx[1] = rb[3]; nd.ry[0] = rb[1]; nd.ry[1] = rb[4]; nd.rz[0] = rb[2]; nd.rz[1] = rb[5];
     nd.left = encode_child(c.x, ranges); nd.right = encode_child(c.y, ranges);
     nd.pad0 = nd.pad1 = 0;
     out[i] = nd;
@@ -267,7 +268,8 @@ __global__ void k_ploc_emit(int n, const Box6 *box, const int *left, const int *
     int l = left[id], r = right[id];
     Box6 lb = box[l], rb = box[r];
     BvhNode nd;
-    for (int a = 0; a < 3; ++a) { nd.lmin[a] = lb.lo[a]; nd.lmax[a] = lb.hi[a]; nd.rmin[a] = rb.lo[a]; nd.rmax[a] = rb.hi[a]; }
+    nd.lx[0] = lb.lo[0]; nd.lx[1] = lb.hi[0]; nd.ly[0] = lb.lo[1]; nd.ly[1] = lb.hi[1]; nd.lz[0] = lb.lo[2]; nd.lz[1] = lb.hi[2];
+    nd.rx[0] = rb.lo[0]; nd.rx[1] = rb.hi[0]; nd.ry[0] = rb.lo[1]; nd.ry[1] = rb.hi[1]; nd.rz[0] = rb.lo[2]; nd.rz[1] = rb.hi[2];
     nd.left = ploc_child_ref(l, n, left, right, parent, count); nd.right = ploc_child_ref(r, n, left, right, parent, count);
     nd.pad0 = nd.pad1 = 0;
     out[i] = nd;
@@ -287,7 +289,8 @@ struct PathState {
 __device__ __forceinline__ void path_begin(PathState &ps) {
     ps.L = mk3(0.f); ps.T = mk3(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
 }
-// returns true when the path ends at this vertex.  `dbg` (tests only): 8 floats per vertex.
+// returns true when the path ends at this vertex.  `dbg` (tests / ray capture only): 16 floats per vertex —
+// [hit inst, prim, bary.xy | light pdf, bsdf pdf towards the light, sampled pdf, occluded | shadow ray o.xyz d.xyz t_max, traced].
 template<bool FULL>
 __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, uint32_t *stack, PathState &ps, Sampler &sampler,
                                             DCounters &cnt, float *dbg) {
@@ -333,7 +336,11 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
     V3 wi = normalize(ls.p_light - it.pos);
     ScatterEval se; BSDFSample bs;
     mat_evaluate_and_sample<FULL>(S, mc, it, wi, sampler, se, bs, cnt);
-    if (dbg) { dbg[4] = ls.eval.pdf; dbg[5] = se.pdf; dbg[6] = bs.eval.pdf; dbg[7] = occluded ? 1.f : 0.f; }
+    if (dbg) {
+        dbg[4] = ls.eval.pdf; dbg[5] = se.pdf; dbg[6] = bs.eval.pdf; dbg[7] = occluded ? 1.f : 0.f;
+        dbg[8] = shadow_ray.o.x; dbg[9] = shadow_ray.o.y; dbg[10] = shadow_ray.o.z; dbg[11] = shadow_ray.d.x; dbg[12] = shadow_ray.d.y;
+        dbg[13] = shadow_ray.d.z; dbg[14] = shadow_ray.t_max; dbg[15] = 1.f;
+    }
     bool is_delta_light = ls.eval.pdf < 0.f;
     float weight = mis_mode != 1 ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, se.pdf)) : 1.f;
     ls.eval.pdf = is_delta_light ? -ls.eval.pdf : ls.eval.pdf;
@@ -485,6 +492,51 @@ __global__ __launch_bounds__(kBlock) void k_trace(const DScene *scene, uint32_t 
     for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
 }
 
+
+// traversal replay with dynamic ray fetch: finished lanes are refilled from the ray pool as soon as fewer than
+// `exit_below` lanes of the wave are still traversing
+__global__ __launch_bounds__(kBlock) void k_trace_dyn(const DScene *scene, uint32_t n, const float *org, const float *dir, const float *tmax,
+                                                      int any_hit, uint32_t *hit_out, unsigned long long *counters, uint32_t *queue, int exit_below) {
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    const DScene S = *scene;
+    uint32_t *stack = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+    Trav T; T.cur = kTravDone; T.sp = 0; T.found = false; T.any_hit = any_hit != 0;
+    uint32_t ray_id = VMK_INVALID;
+    bool queue_empty = false;
+    for (;;) {
+        // retire finished rays, fetch new ones (one atomic per wave)
+        if (!T.active() && ray_id != VMK_INVALID) {
+            uint4 o = any_hit ? make_uint4(T.found ? 1u : 0u, 0, 0, 0) : make_uint4(T.hit.inst, T.hit.prim, f2u(T.hit.bary.x), f2u(T.hit.bary.y));
+            reinterpret_cast<uint4 *>(hit_out)[ray_id] = o;
+            ray_id = VMK_INVALID;
+        }
+        bool need = !T.active() && !queue_empty;
+        unsigned long long need_mask = __ballot(need);
+        if (need_mask) {
+            uint32_t base = 0;
+            int leader = __ffsll((long long) need_mask) - 1;
+            if ((int) lane == leader) base = atomicAdd(queue, (uint32_t) __popcll(need_mask));
+            base = __shfl(base, leader, 64);
+            if (need) {
+                uint32_t i = base + (uint32_t) __popcll(need_mask & ((1ull << lane) - 1ull));
+                if (i >= n) queue_empty = true;
+                else {
+                    ray_id = i;
+                    Ray r = {mk3(org[i], org[n + i], org[2 * n + i]), mk3(dir[i], dir[n + i], dir[2 * n + i]), tmax[i]};
+                    trav_begin(T, S, r, any_hit != 0);
+                    if (any_hit) cnt.shadow++; else cnt.closest++;
+                }
+            }
+        }
+        if (!__any(T.active())) break;
+        trav_run(T, S, stack, kBlock, cnt, __any(queue_empty) ? 1 : exit_below); // pool drained: run to completion
+    }
+    uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
+    for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if (lane == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
+}
+
 __device__ __forceinline__ float tone1(uint32_t tm, float x) { // tonemapper/impl.cpp:16-45
     if (tm == 1) { float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f; return saturate_((x * (a * x + b)) / (x * (c * x + d) + e)); }
     if (tm == 2) return x / (x + 1.f);
@@ -566,12 +618,37 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             smp.start(px, py, frame, 1);
             path_begin(ps);
             for (int v = 0; v < 64; ++v) {
-                float dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 bool end = path_bounce<true>(S, P, s_dyn_stack + threadIdx.x, ps, smp, cnt, dbg);
                 if (v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
                 if (end) break;
             }
             o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z;
+            break;
+        }
+        case 7: { // ray capture of one (pixel, frame) for the traversal replay: o[0] = vertex count, then 16 floats per
+                  // vertex [closest ray o.xyz d.xyz t_max, 1 | shadow ray o.xyz d.xyz t_max, traced]; needs out_stride >= 1 + 16 * 24
+            extern __shared__ uint32_t s_dyn_stack[];
+            const DScene S = *scene;
+            uint32_t px = f2u(a[0]), py = f2u(a[1]), frame = f2u(a[2]);
+            Sampler smp; smp.start(px, py, frame, 0);
+            PathState ps; ps.ray = generate_ray(P, px, py, smp);
+            smp.start(px, py, frame, 1);
+            path_begin(ps);
+            int nv = 0;
+            for (int v = 0; v < 64; ++v) {
+                float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                Ray r = ps.ray;
+                bool end = path_bounce<true>(S, P, s_dyn_stack + threadIdx.x, ps, smp, cnt, dbg);
+                if (v < 24 && P->max_depth > 0) {
+                    float *q = o + 1 + v * 16;
+                    q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = r.t_max; q[7] = 1.f;
+                    for (int k = 0; k < 8; ++k) q[8 + k] = dbg[8 + k];
+                    nv = v + 1;
+                }
+                if (end) break;
+            }
+            o[0] = (float) nv;
             break;
         }
         default: break;
@@ -861,7 +938,9 @@ int vmk_build_accel(vmk_ctx *ctx) {
     float ms = 0.f; (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     cleanup();
 #undef BUILD_TRY
-    if (h_depth + 2 > kStackDepth) { ctx->error = "vmk_build_accel: LBVH depth " + std::to_string(h_depth) + " exceeds the LDS traversal stack (" + std::to_string(kStackDepth) + ")"; return VMK_ERR_UNSUPPORTED; }
+#ifndef VMK_EXPERIMENT_NO_DEPTH_CHECK // tuning builds only: a too-shallow stack silently drops subtrees
+    if (h_depth + 2 > kStackDepth) { ctx->error = "vmk_build_accel: BVH depth " + std::to_string(h_depth) + " exceeds the LDS traversal stack (" + std::to_string(kStackDepth) + ")"; return VMK_ERR_UNSUPPORTED; }
+#endif
     DScene &h = ctx->h_scene;
     h.tri_pos = ctx->tri_pos.p; h.tri_attr = ctx->tri_attr.p; h.tri_lookup = ctx->tri_lookup.p; h.nodes = ctx->nodes.p;
     h.root = n <= (uint32_t) kMaxLeafTris ? (int32_t) ~((uint32_t) 0 | ((n - 1u) << 28)) : root_node;
@@ -869,7 +948,7 @@ int vmk_build_accel(vmk_ctx *ctx) {
     HIP_TRY(hipStreamSynchronize(st));
     ctx->tri_pos_in.release(); ctx->tri_attr_in.release();
     ctx->scene_ready = false; // host copies consumed; a new upload is needed before rebuilding
-    ctx->accel = {(uint32_t) (n > 1 ? n - 1 : 0), n <= (uint32_t) kMaxLeafTris ? 1u : h_leaves, (uint32_t) sizeof(BvhNode), (uint32_t) sizeof(vmk_tri_pos), ms};
+    ctx->accel = {(uint32_t) (n > 1 ? n - 1 : 0), n <= (uint32_t) kMaxLeafTris ? 1u : h_leaves, (uint32_t) sizeof(BvhNode), (uint32_t) sizeof(vmk_tri_pos), ms, (uint32_t) h_depth, (uint32_t) kStackDepth};
     ctx->accel_ready = true;
     return VMK_OK;
 }
@@ -1022,7 +1101,14 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     if (repeats == 0) repeats = 1;
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipEventRecord(ctx->ev0, ctx->stream);
-    for (uint32_t r = 0; r < repeats; ++r) hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p);
+    int dyn = 0;
+    if (const char *v = getenv("VMK_TRACE_DYN")) dyn = atoi(v);
+    for (uint32_t r = 0; r < repeats; ++r) {
+        if (dyn > 0) {
+            (void) hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream);
+            hipLaunchKernelGGL(k_trace_dyn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, dyn);
+        } else hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p);
+    }
     (void) hipEventRecord(ctx->ev1, ctx->stream);
     e = hipMemcpyAsync(hit_out, h.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1036,11 +1122,11 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
 
 int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
     if (!ctx) return VMK_ERR_ARG;
-    if (!n || !in || !out || !in_stride || !out_stride || kind > 6) { ctx->error = "vmk_test_eval: bad argument"; return VMK_ERR_ARG; }
-    static const uint32_t min_in[7] = {4, 2, 2, 8, 12, 3, 3}, min_out[7] = {8, 6, 8, 8, 13, 6, 67};
+    if (!n || !in || !out || !in_stride || !out_stride || kind > 7) { ctx->error = "vmk_test_eval: bad argument"; return VMK_ERR_ARG; }
+    static const uint32_t min_in[8] = {4, 2, 2, 8, 12, 3, 3, 3}, min_out[8] = {8, 6, 8, 8, 13, 6, 67, 1 + 16 * 24};
     if (in_stride < min_in[kind] || out_stride < min_out[kind]) { ctx->error = "vmk_test_eval: stride too small for this kind"; return VMK_ERR_ARG; }
     if (kind == 4 && !ctx->accel_ready) { ctx->error = "vmk_test_eval: kind 4 needs an uploaded scene + accel"; return VMK_ERR_STATE; }
-    if (kind == 6 && (!ctx->accel_ready || !ctx->params_ready)) { ctx->error = "vmk_test_eval: kind 6 needs scene, accel and render params"; return VMK_ERR_STATE; }
+    if ((kind == 6 || kind == 7) && (!ctx->accel_ready || !ctx->params_ready)) { ctx->error = "vmk_test_eval: kinds 6/7 need scene, accel and render params"; return VMK_ERR_STATE; }
     if (kind == 5 && !ctx->params_ready) { ctx->error = "vmk_test_eval: kind 5 needs render params"; return VMK_ERR_STATE; }
     if (kind == 4) { // material ids are validated here: the kernel indexes materials[] with them
         uint32_t n_mat = (uint32_t) ctx->materials.n;
