@@ -27,10 +27,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s mea
 
 def algorithmic_bytes(c, pixels, launches, env_lit, texel_bytes):
     """SURVEY.md §8d / DESIGN.md §measurement: touched bytes of the megakernel, from its in-kernel counters.
-    traversal: 64 B per BVH node record + 48 B per triangle record; per shaded hit: 48 + 64 B triangle records + 52 B
+    traversal: 128 B per BVH4 node record + 48 B per triangle record; per shaded hit: 48 + 64 B triangle records + 52 B
     instance row + >= 32 B material block (lower bound: diffuse); per bilinear texture lookup 4 texels; per NEE sample
     the alias entries (12 B each) and, for the environment light, 4 RGBA32F texels; film: 16 B read + 16 B write."""
-    trav = c["nodes_visited"] * 64 + c["tris_tested"] * 48
+    trav = c["nodes_visited"] * 128 + c["tris_tested"] * 48
     hit = c["surface_hits"] * (48 + 64 + 52 + 32)
     tex = c["tex_fetches"] * 4 * texel_bytes
     nee = c["shadow_rays"] * ((24 + 8 + 64) if env_lit else (12 + 48 + 64 + 52))

@@ -242,7 +242,7 @@ const char *vmk_last_error(const vmk_ctx *ctx); /* valid until the next call on 
 uint32_t vmk_abi_version(void);
 
 int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *scene);
-int vmk_build_accel(vmk_ctx *ctx); /* GPU build: Morton codes -> radix sort -> PLOC merge rounds -> 64 B BVH2 nodes */
+int vmk_build_accel(vmk_ctx *ctx); /* GPU build: Morton codes -> radix sort -> PLOC merge rounds -> 128 B BVH4 nodes */
 int vmk_set_render_params(vmk_ctx *ctx, const vmk_render_params *params);
 
 /* Film. fb == NULL: the ctx owns a width*height float4 accumulation buffer. Otherwise fb is a DEVICE
@@ -268,8 +268,8 @@ void *vmk_stream(vmk_ctx *ctx); /* hipStream_t the ctx launches on */
 typedef struct vmk_accel_info {
     uint32_t n_nodes, n_leaves, node_bytes, tri_bytes;
     float build_ms;
-    uint32_t depth;       /* internal nodes on the longest root-to-leaf path */
-    uint32_t stack_depth; /* entries of the per-lane LDS traversal stack; builds with depth + 2 > stack_depth are rejected */
+    uint32_t depth;       /* exact worst-case number of pending entries on a ray's traversal stack */
+    uint32_t stack_depth; /* entries of the per-ray LDS traversal stack; builds with depth > stack_depth are rejected */
 } vmk_accel_info;
 int vmk_accel_info_get(vmk_ctx *ctx, vmk_accel_info *out);
 

@@ -75,7 +75,7 @@ def test_material_camera_and_path_units(backend, scene):
 def test_traversal_hits_match_oracle(backend, scene, w, h):
     """GPU LBVH + LDS-stack traversal vs the oracle's own BVH: identical (inst, prim, bary) and occlusion bits."""
     hs, p, osc, info = _load(backend, scene, w, h)
-    assert info["node_bytes"] == 64 and info["tri_bytes"] == 48
+    assert info["node_bytes"] == 128 and info["tri_bytes"] == 48
     rng = np.random.default_rng(5)
     lo, hi = np.array(list(hs.scene.world_min)), np.array(list(hs.scene.world_max))
     n = 20000

@@ -15,7 +15,7 @@ for r in range(reps):
     ms = pipe.render(frames=spp)
     c = pipe.counters()
     rays = c["closest_rays"] + c["shadow_rays"]
-    bytes_trav = c["nodes_visited"] * 64 + c["tris_tested"] * 48
+    bytes_trav = c["nodes_visited"] * 128 + c["tris_tested"] * 48
     print(f"rep {r}: {ms:.2f} ms, {rays / ms / 1e3:.1f} Mrays/s, rays/path {rays / c['paths']:.2f}, nodes/ray {c['nodes_visited'] / rays:.1f}, tris/ray {c['tris_tested'] / rays:.1f}, trav GB/s {bytes_trav / ms / 1e6:.1f}, tex/hit {c['tex_fetches'] / max(c['surface_hits'], 1):.2f}")
 if len(sys.argv) > 6:
     pipe.save_result(sys.argv[6])

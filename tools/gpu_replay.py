@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Traversal-only replay: capture the rays the megakernel itself traces on classroom (k_test kind 7: one
 frame of every 16th 32x32 tile, in the lane order of the megakernel's waves) and replay them through k_trace.
-Prints one line per ray class with Mrays/s and algorithmic GB/s (64 B per node record, 48 B per triangle record,
+Prints one line per ray class with Mrays/s and algorithmic GB/s (128 B per node record, 48 B per triangle record,
 44 B per ray in/out) against the 8 TB/s HBM peak.   usage: gpu_replay.py [scene.json] [width height] [tile_step]"""
 import os, sys, json
 import numpy as np
@@ -34,7 +34,7 @@ def replay(pipe, step=16, frame=0, repeats=5):
         _, ms = be.trace(rays["org"][m], rays["dir"][m], rays["tmax"][m], any_hit=bool(kind), repeats=repeats)
         c = be.counters()
         traced = c["closest_rays"] + c["shadow_rays"]
-        b = (c["nodes_visited"] * 64 + c["tris_tested"] * 48 + traced * 44) / repeats
+        b = (c["nodes_visited"] * 128 + c["tris_tested"] * 48 + traced * 44) / repeats
         res[name] = {"rays": n, "ms": ms, "mrays_s": n / ms / 1e3, "nodes_per_ray": c["nodes_visited"] / traced,
                      "tris_per_ray": c["tris_tested"] / traced, "algorithmic_GBs": b / ms / 1e6, "frac_of_8TBs": b / ms / 1e6 / 8000.0}
     return res

@@ -22,5 +22,5 @@ for name, o, dd, anyhit, tm in (("primary closest", cam[:, :3], cam[:, 3:], Fals
     h, ms = be.trace(o, dd, np.full(n, tm, np.float32), any_hit=anyhit, repeats=5)
     c = be.counters()
     rays = c["closest_rays"] + c["shadow_rays"]
-    b = c["nodes_visited"] * 64 + c["tris_tested"] * 48 + rays * 44
+    b = c["nodes_visited"] * 128 + c["tris_tested"] * 48 + rays * 44
     print(f"{name}: {ms:.3f} ms/launch, {n / ms / 1e3:.0f} Mrays/s, nodes/ray {c['nodes_visited'] / rays:.1f}, tris/ray {c['tris_tested'] / rays:.1f}, algorithmic {b / 5 / ms / 1e6:.0f} GB/s ({b / 5 / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s), hit frac {(h[:, 0] != 0xFFFFFFFF).mean() if not anyhit else (h[:, 0] == 1).mean():.2f}")

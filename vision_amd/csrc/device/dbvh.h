@@ -1,22 +1,38 @@
-// dbvh.h — BVH2 traversal with a per-lane short stack in LDS (wave64; stack[d][lane] layout => conflict-free banks).
+// dbvh.h — wave-cooperative BVH4 traversal: 4 lanes per ray, 16 rays in flight per wave64.
 // Replaces ocarina::Accel trace_closest / trace_occlusion (base/mgr/geometry.cpp:168-185; OptiX in the reference).
 // Hit selection rule (shared with the oracle): valid hits 0 < t < t_max, smallest t wins, equal t resolved towards
 // the smaller (inst, prim).  Triangle test: Moeller-Trumbore on world-space vertices, IEEE float32, no contraction.
+//
+// Why quads.  With one ray per lane (the first design) the counters on classroom read: 12.9 of 64 lanes
+// active per VALU op and the texture-addresser (TA) 73 % busy — a wave64 memory instruction occupies the TA for ~19
+// cycles however few lanes are live, and a 64 B BVH2 node cost each lane 4 of them.  Here the 4 lanes of a quad own ONE
+// ray: on an internal node lane q loads and tests child q (2 x 16 B per lane, one 128 B line per quad), the quad orders
+// its hits with three DPP quad_perm reads and pushes the far ones onto the ray's stack in LDS; on a leaf lane q tests
+// triangle q.  A wave serves its 64 rays through 16 quads that pull the next ray from an LDS list as soon as their ray
+// retires, so lanes whose path is dead or short cost nothing.
 #pragma once
 #include "dpath.h"
 
 namespace vmkd {
 
-// Traversal stack: LDS only, stack[level][thread] (stride = block size, so consecutive lanes hit consecutive banks).
-// 40 levels x 4 B = 10 KB per wave -> 16 waves per CU fit in 160 KB.  The depth of a built tree is checked against
-// kStackDepth at build time.  (Measured alternatives on classroom: spilling deep levels to a per-lane private array
-// costs 28 % — 1920 -> 1373 Mrays/s — and 48 LDS levels at 2 blocks/CU cost 41 %.)
-#ifndef VMK_STACK_DEPTH
-#define VMK_STACK_DEPTH 40
-#endif
-constexpr int kStackDepth = VMK_STACK_DEPTH;
+constexpr int kQuadStack = 64; // stack entries per ray; a build whose worst-case need exceeds it is rejected
+constexpr int32_t kTravDone = 0x7fffffff;
 
 struct Hit { uint32_t inst, prim, tri; V2 bary; };
+
+// one per wave, in LDS (6.25 KB): staged rays / returned hits by lane, the list of lanes that have a ray, 16 ray stacks
+struct WaveScratch {
+    float4 ray[64][2];              // in: {o.xyz, t_max} {d.xyz, any_hit}   out (same slot): {inst, prim, tri, found} {u, v, -, -}
+    uint32_t stack[kQuadStack][16]; // [level][quad]: the 16 quads of a wave hit 16 different banks
+    uint32_t list[64];              // lanes with an active ray, compacted
+};
+
+// DPP quad permutes (full rate, no LDS traffic).  Every use sits in quad-uniform control flow.
+template<int CTRL> VD int32_t quad_perm_i(int32_t v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template<int CTRL> VD float quad_perm_f(float v) { return u2f((uint32_t) __builtin_amdgcn_mov_dpp((int32_t) f2u(v), CTRL, 0xf, 0xf, true)); }
+constexpr int kQuadXor1 = 0xB1; // quad_perm:[1,0,3,2]
+constexpr int kQuadXor2 = 0x4E; // quad_perm:[2,3,0,1]
+constexpr int kQuadXor3 = 0x1B; // quad_perm:[3,2,1,0]
 
 VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, V3 d, float *t_out, float *u_out, float *v_out, uint32_t *inst_out, uint32_t *prim_out) {
     // 48 B record as three 16 B loads
@@ -41,10 +57,9 @@ VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, V3 d, float *t_out, float *u_
 }
 
 // conservative slab test; NaN slabs (0 * inf) are ignored by the min/max (IEEE minNum/maxNum on v_min/v_max_f32).
-// Measured and rejected: t = fma(b, inv, -o*inv) saves 12 VALU ops per node but is not conservative for rays that
+// The node stores each slab as a (min, max) pair so that both planes of a slab go through one v_pk_add_f32 + one
+// v_pk_mul_f32 (gfx950 packed fp32).  Measured and rejected: t = fma(b, inv, -o*inv) is not conservative for rays that
 // start on a box face (every bounce ray does): its absolute error |o*inv|*2^-24 is unbounded relative to (b-o)*inv.
-// The node stores each slab as a (min, max) pair so that both planes of a slab go through one v_pk_add_f32 +
-// one v_pk_mul_f32 (gfx950 packed fp32): 6 + 6 instead of 12 + 12 VALU ops per node for the plane distances.
 VD bool hit_box(f2v bx, f2v by, f2v bz, V3 o, V3 inv, float t_far, float *t_near_out) {
     f2v tx = (bx - o.x) * inv.x, ty = (by - o.y) * inv.y, tz = (bz - o.z) * inv.z;
     float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), 0.f));
@@ -53,128 +68,165 @@ VD bool hit_box(f2v bx, f2v by, f2v bz, V3 o, V3 inv, float t_far, float *t_near
     return tn * 0.999999f <= tf * 1.000001f;
 }
 
-// `stack` points at this lane's column of the block's LDS stack; consecutive levels are `stride` words apart.
-template<bool ANY_HIT>
-VD bool traverse(const DScene &S, const Ray &r, uint32_t *stack, int stride, Hit &hit, DCounters &cnt) {
-    V3 inv = {1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z};
-    float best_t = r.t_max;
-    hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
-    if (S.n_tris == 0) return false;
-    constexpr int32_t kDone = 0x7fffffff;
-    int sp = 0;
-    int32_t cur = S.root;
-    uint32_t nn = 0, nt = 0;
-    bool found = false;
-    // "while-while": all lanes of the wave first descend through internal nodes, then the lanes that reached a leaf test
-    // their triangles together — fewer serialised node/leaf branches per wave (+14 % Mrays/s on classroom).
-    while (cur != kDone) {
-        while (cur >= 0 && cur != kDone) {
-            const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
-            float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
-            ++nn;
-            int32_t left = (int32_t) f2u(n3.x), right = (int32_t) f2u(n3.y);
-            float tl, tr;
-            bool hl = hit_box(f2v{n0.x, n0.y}, f2v{n0.z, n0.w}, f2v{n1.x, n1.y}, r.o, inv, best_t, &tl);
-            bool hr = hit_box(f2v{n1.z, n1.w}, f2v{n2.x, n2.y}, f2v{n2.z, n2.w}, r.o, inv, best_t, &tr);
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                if (sp < kStackDepth) { stack[sp * stride] = (uint32_t) (left_first ? right : left); ++sp; }
-                cur = left_first ? left : right;
-            } else if (hl) cur = left;
-            else if (hr) cur = right;
-            else if (sp > 0) { --sp; cur = (int32_t) stack[sp * stride]; }
-            else cur = kDone;
-        }
-        if (cur != kDone) {
-            uint32_t v = ~(uint32_t) cur;
-            uint32_t first = v & kLeafFirstMask, count = (v >> 28) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const vmk_tri_pos *tp = S.tri_pos + first + i;
-                float t, u, w;
-                uint32_t inst, prim;
-                ++nt;
-                if (!intersect_tri(tp, r.o, r.d, &t, &u, &w, &inst, &prim)) continue;
-                if (!(t > 0.f && t < r.t_max)) continue;
-                if constexpr (ANY_HIT) { found = true; break; }
-                bool better = !found ? (t <= best_t) : (t < best_t || (t == best_t && (inst < hit.inst || (inst == hit.inst && prim < hit.prim))));
-                if (better) { best_t = t; hit.inst = inst; hit.prim = prim; hit.tri = first + i; hit.bary = {u, w}; found = true; }
-            }
-            if (ANY_HIT && found) break;
-            if (sp > 0) { --sp; cur = (int32_t) stack[sp * stride]; }
-            else cur = kDone;
-        }
-    }
-    cnt.nodes += nn; cnt.tris += nt;
-    return found;
+VD void wave_lds_fence() { // LDS written by other lanes of this wave is visible after this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Resumable traversal.  Incoherent rays of one wave need very different numbers of steps (measured on classroom:
-// 13-14 of 64 lanes active per VALU instruction in the run-to-completion loop).  The state of a lane's traversal
-// therefore lives in a struct that survives leaving the loop: trav_run() returns as soon as fewer than `exit_below`
-// lanes of the wave are still traversing, the caller refills the idle lanes (new rays / next path vertex) and calls
-// trav_run() again; unfinished lanes simply continue.  Closest-hit and any-hit rays share the one loop.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int32_t kTravDone = 0x7fffffff;
-struct Trav {
-    V3 o, d, inv;
-    float t_max, best_t;
-    int32_t cur;
-    int sp;
-    bool any_hit, found;
-    Hit hit;
-    VD bool active() const { return cur != kTravDone; }
-};
-VD void trav_begin(Trav &T, const DScene &S, const Ray &r, bool any_hit) {
-    T.o = r.o; T.d = r.d; T.inv = {1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z};
-    T.t_max = r.t_max; T.best_t = r.t_max;
-    T.cur = S.n_tris ? S.root : kTravDone; T.sp = 0; T.any_hit = any_hit; T.found = false;
-    T.hit.inst = VMK_INVALID; T.hit.prim = VMK_INVALID; T.hit.tri = VMK_INVALID; T.hit.bary = {0.f, 0.f};
-}
-VD void trav_run(Trav &T, const DScene &S, uint32_t *stack, int stride, DCounters &cnt, int exit_below) {
+#ifndef VMK_NODE_QUADS_MIN
+#define VMK_NODE_QUADS_MIN 8 // leave the node phase when fewer quads than this are on internal nodes and others wait
+#endif
+#ifndef VMK_REFILL_QUADS_MIN
+#define VMK_REFILL_QUADS_MIN 4 // hand back hits / take new rays once this many quads are idle (or nothing else is left)
+#endif
+
+// Trace the rays of all lanes of the wave.  EVERY lane of the wave must call this (convergently); `active` says whether
+// the lane has a ray.  any_hit rays stop at the first valid hit (occlusion query), the others return the closest hit.
+// Returns found; `hit` is filled for closest-hit rays.
+//
+// Loop structure ("while-while" with one postponed leaf per ray): the wave alternates between a node phase, in which
+// every quad that sits on an internal node takes steps, and a leaf phase.  A quad that reaches a leaf parks it in
+// `pend` and keeps descending with the next stack entry, so the node phase only loses a quad when it holds two leaves;
+// the price is that the parked leaf cannot tighten best_t for the nodes visited meanwhile.  Hits are handed back and new
+// rays taken in batches (VMK_REFILL_QUADS_MIN) because that block costs as much as a node step for the whole wave.
+VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, WaveScratch *ws, Hit &hit, DCounters &cnt) {
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
+    hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
+    if (S.n_tris == 0) return false;
+    // ---- stage the rays of the active lanes ----
+    const unsigned long long act_mask = __ballot(active);
+    const uint32_t n_act = (uint32_t) __popcll(act_mask);
+    if (n_act == 0) return false;
+    if (active) {
+        ws->ray[lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.t_max);
+        ws->ray[lane][1] = make_float4(r.d.x, r.d.y, r.d.z, any_hit ? 1.f : 0.f);
+        ws->list[__popcll(act_mask & ((1ull << lane) - 1ull))] = lane;
+    }
+    wave_lds_fence();
+    // ---- per-quad traversal state, replicated in the quad's 4 lanes ----
+    int32_t cur = kTravDone;         // internal node (0 <= cur < kEmptyRef), leaf (< 0) or kTravDone
+    int32_t pend = kTravDone;        // parked leaf or kTravDone
+    int sp = 0;
+    int owner = -1;
+    uint32_t next = 0;               // wave-uniform: next unclaimed entry of ws->list
+    V3 o = mk3(0.f), d = mk3(0.f), inv = mk3(0.f);
+    float t_max = 0.f, best_t = 0.f; // best_t: quad-wide culling bound
+    bool anyh = false;
+    // lane-local best candidate (merged across the quad when the ray retires)
+    float bt = 0.f, bu = 0.f, bv = 0.f;
+    uint32_t binst = VMK_INVALID, bprim = VMK_INVALID, btri = VMK_INVALID;
+    bool found = false;
     uint32_t nn = 0, nt = 0;
+    // lane-constant tie-break bits for the child ordering: does quad lane (q ^ k) come before me?
+    const bool before1 = (q ^ 1u) < q, before2 = (q ^ 2u) < q, before3 = (q ^ 3u) < q;
+#define VMK_POP() do { if (sp > 0) { --sp; cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
+
     for (;;) {
-        bool act = T.cur != kTravDone;
-        int n_act = __popcll(__ballot(act));
-        if (n_act == 0 || n_act < exit_below) break;
-        while (T.cur >= 0 && T.cur != kTravDone) {
-            const float4 *q = reinterpret_cast<const float4 *>(S.nodes + T.cur);
-            float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
-            ++nn;
-            int32_t left = (int32_t) f2u(n3.x), right = (int32_t) f2u(n3.y);
-            float tl, tr;
-            bool hl = hit_box(f2v{n0.x, n0.y}, f2v{n0.z, n0.w}, f2v{n1.x, n1.y}, T.o, T.inv, T.best_t, &tl);
-            bool hr = hit_box(f2v{n1.z, n1.w}, f2v{n2.x, n2.y}, f2v{n2.z, n2.w}, T.o, T.inv, T.best_t, &tr);
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                if (T.sp < kStackDepth) { stack[T.sp * stride] = (uint32_t) (left_first ? right : left); ++T.sp; }
-                T.cur = left_first ? left : right;
-            } else if (hl) T.cur = left;
-            else if (hr) T.cur = right;
-            else if (T.sp > 0) { --T.sp; T.cur = (int32_t) stack[T.sp * stride]; }
-            else T.cur = kTravDone;
+        // ================= node phase =================
+        for (bool first = true;; first = false) {
+            const bool at_node = (uint32_t) cur < (uint32_t) kEmptyRef;
+            const unsigned long long nmask = __ballot(at_node);
+            if (nmask == 0) break;
+            if (!first && __popcll(nmask) < 4 * VMK_NODE_QUADS_MIN) {
+                const bool waiting = !at_node && (pend != kTravDone || cur < 0 || owner >= 0 || next < n_act);
+                if (__any(waiting)) break;
+            }
+            if (at_node) { // lane q tests child q
+                const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur) + q * 2u;
+                float4 a = p[0], b = p[1];
+                int32_t ref = (int32_t) f2u(b.z);
+                float tn;
+                bool h = hit_box(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, o, inv, best_t, &tn) && ref != kEmptyRef;
+                nn += q == 0 ? 1u : 0u;
+                float t = h ? tn : __builtin_inff(); // misses are never ranked before a hit
+                float t1 = quad_perm_f<kQuadXor1>(t), t2 = quad_perm_f<kQuadXor2>(t), t3 = quad_perm_f<kQuadXor3>(t);
+                int rank = ((t1 < t || (t1 == t && before1)) ? 1 : 0) + ((t2 < t || (t2 == t && before2)) ? 1 : 0) + ((t3 < t || (t3 == t && before3)) ? 1 : 0);
+                int n = h ? 1 : 0;
+                n += quad_perm_i<kQuadXor1>(n);
+                n += quad_perm_i<kQuadXor2>(n);
+                int32_t cand = (h && rank == 0) ? ref : (int32_t) 0x80000000;
+                cand = max(cand, quad_perm_i<kQuadXor1>(cand));
+                cand = max(cand, quad_perm_i<kQuadXor2>(cand));
+                if (h && rank > 0) { // far children: the nearest of them ends up on top
+                    int slot = sp + (n - 1 - rank);
+                    if (slot < kQuadStack) ws->stack[slot][quad] = (uint32_t) ref;
+                }
+                if (n > 0) { cur = cand; sp = min(sp + n - 1, kQuadStack); }
+                else VMK_POP();
+                if (cur < 0 && pend == kTravDone) { pend = cur; VMK_POP(); } // park the leaf, keep descending
+            }
         }
-        if (T.cur != kTravDone) {
-            uint32_t v = ~(uint32_t) T.cur;
+        // ================= leaf phase: lane q tests triangle q of the parked leaf =================
+        if (pend != kTravDone) {
+            uint32_t v = ~(uint32_t) pend;
             uint32_t first = v & kLeafFirstMask, count = (v >> 28) + 1u;
-            bool stop = false;
-            for (uint32_t i = 0; i < count; ++i) {
-                const vmk_tri_pos *tp = S.tri_pos + first + i;
+            if (q < count) {
                 float t, u, w;
                 uint32_t inst, prim;
                 ++nt;
-                if (!intersect_tri(tp, T.o, T.d, &t, &u, &w, &inst, &prim)) continue;
-                if (!(t > 0.f && t < T.t_max)) continue;
-                if (T.any_hit) { T.found = true; stop = true; break; }
-                bool better = !T.found ? (t <= T.best_t) : (t < T.best_t || (t == T.best_t && (inst < T.hit.inst || (inst == T.hit.inst && prim < T.hit.prim))));
-                if (better) { T.best_t = t; T.hit.inst = inst; T.hit.prim = prim; T.hit.tri = first + i; T.hit.bary = {u, w}; T.found = true; }
+                if (intersect_tri(S.tri_pos + first + q, o, d, &t, &u, &w, &inst, &prim) && t > 0.f && t < t_max) {
+                    bool better = !found || t < bt || (t == bt && (inst < binst || (inst == binst && prim < bprim)));
+                    if (better) { found = true; bt = t; binst = inst; bprim = prim; btri = first + q; bu = u; bv = w; }
+                }
             }
-            if (stop) T.cur = kTravDone;
-            else if (T.sp > 0) { --T.sp; T.cur = (int32_t) stack[T.sp * stride]; }
-            else T.cur = kTravDone;
+            float m = found ? bt : t_max;
+            m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
+            m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
+            best_t = m;
+            pend = kTravDone;
+            if (anyh && m < t_max) cur = kTravDone; // occlusion query: some lane of the quad has a hit
         }
+        if (cur < 0) { pend = cur; VMK_POP(); } // a second leaf was waiting: park it for the next leaf phase
+        // ================= hand back hits, take new rays =================
+        const bool idle = cur == kTravDone && pend == kTravDone;
+        const bool want = idle && (owner >= 0 || next < n_act);
+        const unsigned long long want_mask = __ballot(want);
+        const bool any_busy = __any(!idle);
+        if (want_mask == 0) { if (!any_busy) break; continue; }
+        if (any_busy && __popcll(want_mask) < 4 * VMK_REFILL_QUADS_MIN) continue;
+        if (idle && owner >= 0) { // ---- retire: merge the 4 lane-local candidates, lane 0 returns the hit ----
+#define VMK_QUAD_MERGE(CTRL) { \
+            int32_t of = quad_perm_i<CTRL>(found ? 1 : 0); float ot = quad_perm_f<CTRL>(bt); \
+            uint32_t oi = (uint32_t) quad_perm_i<CTRL>((int32_t) binst), op = (uint32_t) quad_perm_i<CTRL>((int32_t) bprim), otr = (uint32_t) quad_perm_i<CTRL>((int32_t) btri); \
+            float ou = quad_perm_f<CTRL>(bu), ov = quad_perm_f<CTRL>(bv); \
+            bool take = of && (!found || ot < bt || (ot == bt && (oi < binst || (oi == binst && op < bprim)))); \
+            if (take) { found = true; bt = ot; binst = oi; bprim = op; btri = otr; bu = ou; bv = ov; } }
+            VMK_QUAD_MERGE(kQuadXor1)
+            VMK_QUAD_MERGE(kQuadXor2)
+#undef VMK_QUAD_MERGE
+            if (q == 0) {
+                ws->ray[owner][0] = make_float4(u2f(binst), u2f(bprim), u2f(btri), found ? 1.f : 0.f);
+                ws->ray[owner][1] = make_float4(bu, bv, 0.f, 0.f);
+            }
+            owner = -1;
+        }
+        const unsigned long long idle_mask = __ballot(idle && q == 0);
+        if (idle) { // ---- refill from the list ----
+            uint32_t idx = next + (uint32_t) __popcll(idle_mask & ((1ull << (lane & ~3u)) - 1ull));
+            if (idx < n_act) {
+                owner = (int) ws->list[idx];
+                float4 a = ws->ray[owner][0], b = ws->ray[owner][1];
+                o = mk3(a.x, a.y, a.z); t_max = a.w; d = mk3(b.x, b.y, b.z); anyh = b.w != 0.f;
+                // v_rcp_f32 (1 ulp) is enough here: inv only feeds the padded, conservative slab test
+                inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
+                best_t = t_max; cur = S.root; sp = 0;
+                found = false; bt = t_max; binst = VMK_INVALID; bprim = VMK_INVALID; btri = VMK_INVALID; bu = 0.f; bv = 0.f;
+            }
+        }
+        next = min(next + (uint32_t) __popcll(idle_mask), n_act);
     }
+#undef VMK_POP
     cnt.nodes += nn; cnt.tris += nt;
+    wave_lds_fence();
+    bool res = false;
+    if (active) {
+        float4 a = ws->ray[lane][0], b = ws->ray[lane][1];
+        res = a.w != 0.f;
+        if (res) { hit.inst = f2u(a.x); hit.prim = f2u(a.y); hit.tri = f2u(a.z); hit.bary = {b.x, b.y}; }
+    }
+    wave_lds_fence(); // the scratch is restaged by the next call
+    return res;
 }
 
 }// namespace vmkd

@@ -7,16 +7,19 @@ namespace vmkd {
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-// BVH2 node, 64 B = one S_node record: both child AABBs live in the parent so one fetch decides both
-// children.  Each slab is a (min, max) pair — the operand shape of the packed-fp32 slab test in dbvh.h.  child >= 0: internal node index.  child < 0: leaf, v = ~child, first triangle = v & 0x0fffffff (index
-// into the Morton-ordered triangle arrays), count = (v >> 28) + 1.
-struct alignas(16) BvhNode {
-    float lx[2], ly[2], lz[2]; // left child:  (min, max) per axis
-    float rx[2], ry[2], rz[2]; // right child
-    int32_t left, right;
-    uint32_t pad0, pad1;
+// BVH4 node, 128 B = one cache line = one S_node record.  Child-major: child c occupies bytes
+// [32c, 32c+32) so that lane c of a traversal quad fetches its child with two 16 B loads and the quad's 4 lanes cover the
+// line.  Each slab is a (min, max) pair — the operand shape of the packed-fp32 slab test in dbvh.h.
+// ref >= 0: internal node index.  ref == kEmptyRef: unused slot.  ref < 0: leaf, v = ~ref, first triangle = v & 0x0fffffff
+// (index into the depth-first ordered triangle arrays), count = (v >> 28) + 1 (<= kMaxLeafTris = one triangle per lane).
+struct alignas(16) BvhChild {
+    float x[2], y[2], z[2];
+    int32_t ref;
+    uint32_t pad;
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 B");
+struct alignas(128) BvhNode { BvhChild child[4]; };
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 B");
+constexpr int32_t kEmptyRef = 0x7ffffffe;
 constexpr uint32_t kLeafFirstMask = 0x0fffffffu;
 constexpr int kMaxLeafTris = 4;
 
@@ -35,7 +38,7 @@ struct DScene {
     const float *srgb_lut; // 256-entry sRGB EOTF table (8-bit texel -> linear)
     const float *lut_pure_reflection, *lut_dielectric, *lut_dielectric_inv, *lut_specular, *lut_coat, *lut_sheen_approx;
     const BvhNode *nodes;
-    int32_t root; // child-encoded reference of the root (leaf-encoded when the scene has <= kMaxLeafTris triangles)
+    int32_t root; // reference of the root: node 0, or leaf-encoded when the scene has <= kMaxLeafTris triangles
     uint32_t n_tris, n_lights, env_light;
 };
 

@@ -1,10 +1,11 @@
 // vmk.hip — libvmk.so: the gfx950 path-tracing backend behind include/vmk.h.
 //
 // Kernels (all hand-written HIP, wave64):
-//   k_render         the megakernel: ray-gen -> LDS-stack BVH traversal -> polymorphic BSDF eval/sample -> NEE ->
-//                    Russian roulette -> in-register film accumulation; persistent lanes pull (pixel) work items with
-//                    a wavefront ballot so finished lanes are refilled instead of idling.
-//   k_morton / k_karras / k_refit / k_emit   GPU LBVH build (Morton codes -> radix sort -> Karras hierarchy -> refit)
+//   k_render         the megakernel: ray-gen -> wave-cooperative BVH4 traversal (dbvh.h) -> polymorphic BSDF eval/sample ->
+//                    NEE -> Russian roulette -> in-register film accumulation; persistent lanes pull (pixel) work items
+//                    with a wavefront ballot so finished lanes are refilled instead of idling.
+//   k_morton / k_ploc_* / k_bvh4_level   GPU BVH build (63-bit Morton codes -> radix sort -> PLOC merge rounds ->
+//                    depth-first triangle order -> top-down collapse into 128 B BVH4 nodes)
 //   k_trace          traversal-only replay over SoA ray buffers (roofline measurement, parity of hits)
 //   k_tonemap        exposure / tone map / gamma epilogue
 //   k_test           per-function device unit entry points for the parity tests
@@ -73,103 +74,6 @@ __global__ void k_reorder(const uint32_t *vals, uint32_t n, const vmk_tri_pos *p
     attr_out[i] = attr_in[src];
     lookup[src] = i;
 }
-// common-prefix length of sorted keys i and j; equal codes fall back to the position (Karras 2012 §4: unique keys)
-__device__ __forceinline__ int delta_key(const uint64_t *keys, int n, int i, int j) {
-    if (j < 0 || j >= n) return -1;
-    uint64_t x = keys[i] ^ keys[j];
-    if (x == 0) return 64 + __clz((unsigned) (i ^ j));
-    return __clzll((long long) x);
-}
-// Karras 2012, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees": one thread per internal node.
-__global__ void k_karras(const uint64_t *keys, int n, int2 *children, int2 *ranges, int *parent_internal, int *parent_leaf) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    int d = (delta_key(keys, n, i, i + 1) - delta_key(keys, n, i, i - 1)) >= 0 ? 1 : -1;
-    int dmin = delta_key(keys, n, i, i - d);
-    int lmax = 2;
-    while (delta_key(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-    int l = 0;
-    for (int t = lmax / 2; t >= 1; t /= 2) if (delta_key(keys, n, i, i + (l + t) * d) > dmin) l += t;
-    int j = i + l * d;
-    int dnode = delta_key(keys, n, i, j);
-    int s = 0;
-    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
-        if (delta_key(keys, n, i, i + (s + t) * d) > dnode) s += t;
-        if (t == 1) break;
-    }
-    int gamma = i + s * d + min(d, 0);
-    int first = min(i, j), last = max(i, j);
-    // child encoding in the build arrays: >= 0 internal, < 0 leaf ~index
-    int left = (first == gamma) ? ~gamma : gamma;
-    int right = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
-    children[i] = make_int2(left, right);
-    ranges[i] = make_int2(first, last);
-    if (left >= 0) parent_internal[left] = i; else parent_leaf[gamma] = i;
-    if (right >= 0) parent_internal[right] = i; else parent_leaf[gamma + 1] = i;
-    if (i == 0) parent_internal[0] = -1;
-}
-// bottom-up AABB refit: the second thread to reach a node merges its children; also records the tree depth
-__global__ void k_refit(const vmk_tri_pos *tris, int n, const int2 *children, const int *parent_internal, const int *parent_leaf,
-                        float *leaf_box, float *node_box, int *flags) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const vmk_tri_pos &t = tris[i];
-    float b[6];
-    for (int a = 0; a < 3; ++a) { b[a] = fminf(t.p0[a], fminf(t.p1[a], t.p2[a])); b[3 + a] = fmaxf(t.p0[a], fmaxf(t.p1[a], t.p2[a])); }
-    for (int a = 0; a < 6; ++a) __hip_atomic_store(leaf_box + (size_t) i * 6 + a, b[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n == 1) return;
-    __threadfence();
-    int node = parent_leaf[i];
-    while (node >= 0) {
-        if (atomicAdd(&flags[node], 1) == 0) return; // first arrival: sibling subtree not finished
-        __threadfence();
-        int2 c = children[node];
-        const float *lb = c.x >= 0 ? node_box + (size_t) c.x * 6 : leaf_box + (size_t) (~c.x) * 6;
-        const float *rb = c.y >= 0 ? node_box + (size_t) c.y * 6 : leaf_box + (size_t) (~c.y) * 6;
-        float nb[6];
-        // agent-scope (sc1) loads/stores: the sibling's box was written by another CU (per-CU L1s are not coherent)
-        auto ld = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        for (int a = 0; a < 3; ++a) { nb[a] = fminf(ld(lb + a), ld(rb + a)); nb[3 + a] = fmaxf(ld(lb + 3 + a), ld(rb + 3 + a)); }
-        for (int a = 0; a < 6; ++a) __hip_atomic_store(node_box + (size_t) node * 6 + a, nb[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        node = parent_internal[node];
-    }
-}
-__global__ void k_depth(int n, const int *parent_internal, const int *parent_leaf, const int2 *ranges, int *max_depth) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int depth = 0;
-    int node = n > 1 ? parent_leaf[i] : -1;
-    while (node >= 0) { int2 r = ranges[node]; if (r.y - r.x + 1 > kMaxLeafTris) ++depth; node = parent_internal[node]; }
-    atomicMax(max_depth, depth);
-}
-__device__ __forceinline__ int32_t encode_child(int c, const int2 *ranges) {
-    if (c < 0) { uint32_t leaf = (uint32_t) (~c); return (int32_t) ~(leaf & kLeafFirstMask); } // single triangle
-    int2 r = ranges[c];
-    int count = r.y - r.x + 1;
-    if (count <= kMaxLeafTris) return (int32_t) ~(((uint32_t) r.x & kLeafFirstMask) | ((uint32_t) (count - 1) << 28));
-    return c;
-}
-// final 64 B nodes: child boxes pulled into the parent, subtrees of <= kMaxLeafTris triangles collapsed into leaves
-__global__ void k_emit(int n, const int2 *children, const int2 *ranges, const float *leaf_box, const float *node_box, BvhNode *out, uint32_t *n_leaves) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    int2 c = children[i];
-    const float *lb = c.x >= 0 ? node_box + (size_t) c.x * 6 : leaf_box + (size_t) (~c.x) * 6;
-    const float *rb = c.y >= 0 ? node_box + (size_t) c.y * 6 : leaf_box + (size_t) (~c.y) * 6;
-    BvhNode nd;
-    nd.lx[0] = lb[0]; nd.lx[1] = lb[3]; nd.ly[0] = lb[1]; nd.ly[1] = lb[4]; nd.lz[0] = lb[2]; nd.lz[1] = lb[5];
-    nd.rx[0] = rb[0]; nd.rx[1] = rb[3]; nd.ry[0] = rb[1]; nd.ry[1] = rb[4]; nd.rz[0] = rb[2]; nd.rz[1] = rb[5];
-    nd.left = encode_child(c.x, ranges); nd.right = encode_child(c.y, ranges);
-    nd.pad0 = nd.pad1 = 0;
-    out[i] = nd;
-    int2 r = ranges[i];
-    if (r.y - r.x + 1 > kMaxLeafTris) { // live node: count its leaf children
-        uint32_t k = (nd.left < 0 ? 1u : 0u) + (nd.right < 0 ? 1u : 0u);
-        if (k) atomicAdd(n_leaves, k);
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------
 // PLOC hierarchy (Meister & Bittner 2018, "Parallel Locally-Ordered Clustering for BVH Construction") on the
@@ -233,48 +137,75 @@ __global__ void k_ploc_merge(int m, const int *cl, const int *nn, const unsigned
     } else cl_out[pos] = cl[i];
 }
 // depth-first triangle order: position of a node's first leaf = sum of the left-sibling sizes on its root path
-__device__ __forceinline__ int ploc_first(int c, const int *left, const int *right, const int *parent, const int *count, int *live_depth) {
-    int pos = 0, d = 0;
-    for (int p = parent[c]; p >= 0; c = p, p = parent[p]) {
+__device__ __forceinline__ int ploc_first(int c, const int *left, const int *right, const int *parent, const int *count) {
+    int pos = 0;
+    for (int p = parent[c]; p >= 0; c = p, p = parent[p])
         if (right[p] == c) pos += count[left[p]];
-        if (count[p] > kMaxLeafTris) ++d;
-    }
-    if (live_depth) *live_depth = d;
     return pos;
 }
 __global__ void k_ploc_place(int n, const int *left, const int *right, const int *parent, const int *count, const uint32_t *orig,
                              const vmk_tri_pos *pos_in, const vmk_tri_attr *attr_in, vmk_tri_pos *pos_out, vmk_tri_attr *attr_out,
-                             uint32_t *lookup, int *max_depth) {
+                             uint32_t *lookup) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int d;
-    int p = ploc_first(i, left, right, parent, count, &d);
+    int p = ploc_first(i, left, right, parent, count);
     pos_out[p] = pos_in[i]; attr_out[p] = attr_in[i];
     lookup[orig[i]] = (uint32_t) p;
-    atomicMax(max_depth, d);
 }
-__device__ __forceinline__ int32_t ploc_child_ref(int c, int n, const int *left, const int *right, const int *parent, const int *count) {
-    if (count[c] <= kMaxLeafTris) {
-        int first = ploc_first(c, left, right, parent, count, nullptr);
-        return (int32_t) ~(((uint32_t) first & kLeafFirstMask) | ((uint32_t) (count[c] - 1) << 28));
-    }
-    return c - n;
+// ---------------------------------------------------------------------------------------------------------
+// BVH2 -> BVH4 collapse, top-down by levels.  A work item is a binary node that becomes a 4-wide node: its two
+// children are opened (largest surface area first) until four slots are filled or only leaves remain; subtrees of
+// <= kMaxLeafTris triangles become leaves (their triangles are contiguous in the depth-first order, and slots keep the
+// left-to-right order so `first` stays the running sum of the left siblings).  Internal children get their output
+// index from an atomic counter and are queued for the next level.  `acc` carries the stack entries already pending on
+// the path from the root, so max(acc + children - 1) is the exact worst-case traversal stack need.
+// ---------------------------------------------------------------------------------------------------------
+struct Bvh4Work { int id, out, first, acc; };
+__device__ __forceinline__ float box_area(const Box6 &b) {
+    float d0 = b.hi[0] - b.lo[0], d1 = b.hi[1] - b.lo[1], d2 = b.hi[2] - b.lo[2];
+    return d0 * d1 + d1 * d2 + d0 * d2;
 }
-__global__ void k_ploc_emit(int n, const Box6 *box, const int *left, const int *right, const int *parent, const int *count, BvhNode *out, uint32_t *n_leaves) {
+__global__ void k_bvh4_level(const Bvh4Work *in, int n_in, Bvh4Work *out_q, int *out_count, int *node_counter, const Box6 *box,
+                             const int *left, const int *right, const int *count, BvhNode *nodes, uint32_t *n_leaves, int *max_need) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    int id = n + i;
-    if (count[id] <= kMaxLeafTris) return; // collapsed into a leaf of its parent
-    int l = left[id], r = right[id];
-    Box6 lb = box[l], rb = box[r];
+    if (i >= n_in) return;
+    Bvh4Work w = in[i];
+    int slot[4], first[4], ns = 2;
+    slot[0] = left[w.id]; slot[1] = right[w.id];
+    first[0] = w.first; first[1] = w.first + count[slot[0]];
+    while (ns < 4) {
+        int pick = -1; float best = -1.f;
+        for (int k = 0; k < ns; ++k) {
+            if (count[slot[k]] <= kMaxLeafTris) continue;
+            float a = box_area(box[slot[k]]);
+            if (a > best) { best = a; pick = k; }
+        }
+        if (pick < 0) break;
+        for (int k = ns; k > pick + 1; --k) { slot[k] = slot[k - 1]; first[k] = first[k - 1]; }
+        int c = slot[pick];
+        slot[pick] = left[c]; slot[pick + 1] = right[c];
+        first[pick + 1] = first[pick] + count[left[c]];
+        ++ns;
+    }
     BvhNode nd;
-    nd.lx[0] = lb.lo[0]; nd.lx[1] = lb.hi[0]; nd.ly[0] = lb.lo[1]; nd.ly[1] = lb.hi[1]; nd.lz[0] = lb.lo[2]; nd.lz[1] = lb.hi[2];
-    nd.rx[0] = rb.lo[0]; nd.rx[1] = rb.hi[0]; nd.ry[0] = rb.lo[1]; nd.ry[1] = rb.hi[1]; nd.rz[0] = rb.lo[2]; nd.rz[1] = rb.hi[2];
-    nd.left = ploc_child_ref(l, n, left, right, parent, count); nd.right = ploc_child_ref(r, n, left, right, parent, count);
-    nd.pad0 = nd.pad1 = 0;
-    out[i] = nd;
-    uint32_t k = (nd.left < 0 ? 1u : 0u) + (nd.right < 0 ? 1u : 0u);
-    if (k) atomicAdd(n_leaves, k);
+    uint32_t leaves = 0;
+    for (int k = 0; k < 4; ++k) {
+        BvhChild &ch = nd.child[k];
+        ch.pad = 0;
+        if (k >= ns) { ch.x[0] = ch.y[0] = ch.z[0] = 0.f; ch.x[1] = ch.y[1] = ch.z[1] = 0.f; ch.ref = kEmptyRef; continue; }
+        Box6 b = box[slot[k]];
+        ch.x[0] = b.lo[0]; ch.x[1] = b.hi[0]; ch.y[0] = b.lo[1]; ch.y[1] = b.hi[1]; ch.z[0] = b.lo[2]; ch.z[1] = b.hi[2];
+        int c = count[slot[k]];
+        if (c <= kMaxLeafTris) { ch.ref = (int32_t) ~(((uint32_t) first[k] & kLeafFirstMask) | ((uint32_t) (c - 1) << 28)); ++leaves; }
+        else {
+            int o = atomicAdd(node_counter, 1);
+            ch.ref = o;
+            out_q[atomicAdd(out_count, 1)] = {slot[k], o, first[k], w.acc + ns - 1};
+        }
+    }
+    nodes[w.out] = nd;
+    if (leaves) atomicAdd(n_leaves, leaves);
+    atomicMax(max_need, w.acc + ns - 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -289,47 +220,57 @@ struct PathState {
 __device__ __forceinline__ void path_begin(PathState &ps) {
     ps.L = mk3(0.f); ps.T = mk3(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
 }
-// returns true when the path ends at this vertex.  `dbg` (tests / ray capture only): 16 floats per vertex —
+// One path vertex for every lane of the wave: ALL lanes call this convergently (the two traversals inside are
+// wave-cooperative), `active` says whether the lane carries a live path.  Returns true when the lane's path ends at this
+// vertex.  `dbg` (tests / ray capture only): 16 floats per vertex —
 // [hit inst, prim, bary.xy | light pdf, bsdf pdf towards the light, sampled pdf, occluded | shadow ray o.xyz d.xyz t_max, traced].
 template<bool FULL>
-__device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, uint32_t *stack, PathState &ps, Sampler &sampler,
-                                            DCounters &cnt, float *dbg) {
+__device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, WaveScratch *ws, PathState &ps, Sampler &sampler,
+                                            DCounters &cnt, float *dbg, bool active) {
     const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
-    if (max_depth == 0) return true; // `$for(&bounces, 0, max_depth)` never runs
+    if (max_depth == 0) return true; // `$for(&bounces, 0, max_depth)` never runs (uniform: P is a kernel argument)
     Hit hit;
-    cnt.closest++;
-    bool found = traverse<false>(S, ps.ray, stack, kBlock, hit, cnt);
-    if (dbg) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
-    if (!found) { // evaluate_miss integrator.cpp:137-158
+    if (active) cnt.closest++;
+    bool found = traverse_wave(S, ps.ray, active, false, ws, hit, cnt);
+    if (dbg && active) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
+    bool shade = false; // the lane reached a surface with a material: NEE + scattering follow
+    Interaction it;
+    LightSample ls;
+    Ray shadow_ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
+    if (active && !found) { // evaluate_miss integrator.cpp:137-158
         if (S.env_light != VMK_INVALID) {
             LightEval ev = light_evaluate_miss_wi(S, P, ps.ray.o, ps.ray.d, cnt);
             float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
             weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
             ps.L += (ev.L * 1.f * weight) * ps.T;
         }
-        return true;
     }
-    Interaction it;
-    compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
-    it.wo = normalize(-ps.ray.d);
-    if (it.mat_id == VMK_INVALID) { // integrator.cpp:208-214: pass through, bounce not counted
-        ps.ray = spawn_ray(it.pos, it.ng, ps.ray.d);
-        return false;
+    bool pass_through = false;
+    if (active && found) {
+        compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
+        it.wo = normalize(-ps.ray.d);
+        if (it.mat_id == VMK_INVALID) { // integrator.cpp:208-214: pass through, bounce not counted
+            ps.ray = spawn_ray(it.pos, it.ng, ps.ray.d);
+            pass_through = true;
+        } else {
+            cnt.hits++;
+            if (it.light_id != VMK_INVALID) { // integrator.cpp:221-231
+                LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt);
+                float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
+                weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
+                ps.L += ev.L * ps.T * weight * 1.f;
+            }
+            ps.prev_ng = it.ng;
+            // NEE (3 draws) + shadow ray
+            ls = light_sample_wi(S, P, it.pos, sampler, cnt);
+            shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
+            shade = true;
+            cnt.shadow++;
+        }
     }
-    cnt.hits++;
-    if (it.light_id != VMK_INVALID) { // integrator.cpp:221-231
-        LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt);
-        float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
-        weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
-        ps.L += ev.L * ps.T * weight * 1.f;
-    }
-    ps.prev_ng = it.ng;
-    // NEE (3 draws) + shadow ray
-    LightSample ls = light_sample_wi(S, P, it.pos, sampler, cnt);
-    Ray shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
     Hit sh;
-    cnt.shadow++;
-    bool occluded = traverse<true>(S, shadow_ray, stack, kBlock, sh, cnt);
+    bool occluded = traverse_wave(S, shadow_ray, shade, true, ws, sh, cnt);
+    if (!shade) return !pass_through;
     // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
     MatCtx mc;
     mat_prepare<FULL>(S, S.materials + it.mat_id, it, mc, cnt);
@@ -389,11 +330,11 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 template<bool FULL>
 __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = *A.scene;
     const vmk_render_params *P = A.params;
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t *stack = s_stack + threadIdx.x;
+    WaveScratch *ws = s_ws + (threadIdx.x >> 6);
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
 
     const uint32_t frame_end = A.frame_begin + A.frame_count;
@@ -435,10 +376,9 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
             }
         }
         if (!__any(has_pixel || !queue_empty)) break;
-        if (!has_pixel) continue;
 
         // ---- start a new path: ray generation (rt_geom kernel of the reference, frame_buffer.cpp:172-177) ----
-        if (!path_alive) {
+        if (has_pixel && !path_alive) {
             sampler.start(px, py, frame, 0);
             ps.ray = generate_ray(P, px, py, sampler);
             sampler.start(px, py, frame, 1); // path_tracing kernel, integrator.cpp:93
@@ -448,8 +388,9 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
         }
 
         // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
-        bool terminate = path_bounce<FULL>(S, P, stack, ps, sampler, cnt, nullptr);
-        if (terminate) { // RGBFilm accumulation, frame_buffer.cpp:117-126
+        // (all lanes take part: the traversals inside are wave-cooperative; lanes without a pixel contribute no ray)
+        bool terminate = path_bounce<FULL>(S, P, ws, ps, sampler, cnt, nullptr, has_pixel);
+        if (has_pixel && terminate) { // RGBFilm accumulation, frame_buffer.cpp:117-126
             float a = 1.f / (float) (frame + 1u);
             V4 val = {ps.L.x, ps.L.y, ps.L.z, 1.f};
             acc = lerp4(a, acc, val);
@@ -475,66 +416,25 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_trace(const DScene *scene, uint32_t n, const float *org, const float *dir, const float *tmax,
                                                   int any_hit, uint32_t *hit_out, unsigned long long *counters) {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = *scene;
-    uint32_t *stack = s_stack + threadIdx.x;
+    WaveScratch *ws = s_ws + (threadIdx.x >> 6);
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) { // block-uniform trip count
+        uint32_t i = base + threadIdx.x;
+        bool active = i < n;
+        Ray r = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
         // SoA rays: component arrays of length n (coalesced 4 B/lane loads)
-        Ray r = {mk3(org[i], org[n + i], org[2 * n + i]), mk3(dir[i], dir[n + i], dir[2 * n + i]), tmax[i]};
+        if (active) r = {mk3(org[i], org[n + i], org[2 * n + i]), mk3(dir[i], dir[n + i], dir[2 * n + i]), tmax[i]};
         Hit h;
-        uint4 o;
-        if (any_hit) { cnt.shadow++; bool occ = traverse<true>(S, r, stack, kBlock, h, cnt); o = make_uint4(occ ? 1u : 0u, 0, 0, 0); }
-        else { cnt.closest++; traverse<false>(S, r, stack, kBlock, h, cnt); o = make_uint4(h.inst, h.prim, f2u(h.bary.x), f2u(h.bary.y)); }
-        reinterpret_cast<uint4 *>(hit_out)[i] = o;
+        bool found = traverse_wave(S, r, active, any_hit != 0, ws, h, cnt);
+        if (active) {
+            if (any_hit) { cnt.shadow++; reinterpret_cast<uint4 *>(hit_out)[i] = make_uint4(found ? 1u : 0u, 0, 0, 0); }
+            else { cnt.closest++; reinterpret_cast<uint4 *>(hit_out)[i] = make_uint4(h.inst, h.prim, f2u(h.bary.x), f2u(h.bary.y)); }
+        }
     }
     uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
     for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
-}
-
-
-// traversal replay with dynamic ray fetch: finished lanes are refilled from the ray pool as soon as fewer than
-// `exit_below` lanes of the wave are still traversing
-__global__ __launch_bounds__(kBlock) void k_trace_dyn(const DScene *scene, uint32_t n, const float *org, const float *dir, const float *tmax,
-                                                      int any_hit, uint32_t *hit_out, unsigned long long *counters, uint32_t *queue, int exit_below) {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    const DScene S = *scene;
-    uint32_t *stack = s_stack + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
-    Trav T; T.cur = kTravDone; T.sp = 0; T.found = false; T.any_hit = any_hit != 0;
-    uint32_t ray_id = VMK_INVALID;
-    bool queue_empty = false;
-    for (;;) {
-        // retire finished rays, fetch new ones (one atomic per wave)
-        if (!T.active() && ray_id != VMK_INVALID) {
-            uint4 o = any_hit ? make_uint4(T.found ? 1u : 0u, 0, 0, 0) : make_uint4(T.hit.inst, T.hit.prim, f2u(T.hit.bary.x), f2u(T.hit.bary.y));
-            reinterpret_cast<uint4 *>(hit_out)[ray_id] = o;
-            ray_id = VMK_INVALID;
-        }
-        bool need = !T.active() && !queue_empty;
-        unsigned long long need_mask = __ballot(need);
-        if (need_mask) {
-            uint32_t base = 0;
-            int leader = __ffsll((long long) need_mask) - 1;
-            if ((int) lane == leader) base = atomicAdd(queue, (uint32_t) __popcll(need_mask));
-            base = __shfl(base, leader, 64);
-            if (need) {
-                uint32_t i = base + (uint32_t) __popcll(need_mask & ((1ull << lane) - 1ull));
-                if (i >= n) queue_empty = true;
-                else {
-                    ray_id = i;
-                    Ray r = {mk3(org[i], org[n + i], org[2 * n + i]), mk3(dir[i], dir[n + i], dir[2 * n + i]), tmax[i]};
-                    trav_begin(T, S, r, any_hit != 0);
-                    if (any_hit) cnt.shadow++; else cnt.closest++;
-                }
-            }
-        }
-        if (!__any(T.active())) break;
-        trav_run(T, S, stack, kBlock, cnt, __any(queue_empty) ? 1 : exit_below); // pool drained: run to completion
-    }
-    uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
-    for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if (lane == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
 }
 
 __device__ __forceinline__ float tone1(uint32_t tm, float x) { // tonemapper/impl.cpp:16-45
@@ -560,10 +460,12 @@ __global__ void k_tonemap(const float4 *accum, float4 *out, uint32_t n, float ex
 }
 
 __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
+    __shared__ WaveScratch s_ws[1]; // launched with 64-thread blocks
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *a = in + (size_t) i * in_stride;
-    float *o = out + (size_t) i * out_stride;
+    const bool live = i < n;
+    if (!live && kind != 6 && kind != 7) return; // kinds 6/7 trace rays: every lane of the wave has to stay
+    const float *a = in + (size_t) (live ? i : 0) * in_stride;
+    float *o = out + (size_t) (live ? i : 0) * out_stride;
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
     switch (kind) {
         case 0: { Sampler s; s.start(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3])); for (int k = 0; k < 8; ++k) o[k] = s.next_1d(); break; }
@@ -610,25 +512,24 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             break;
         }
         case 6: { // whole path of one (pixel, frame): 8 floats per vertex for up to 8 vertices, then L (3 floats)
-            extern __shared__ uint32_t s_dyn_stack[];
             const DScene S = *scene;
             uint32_t px = f2u(a[0]), py = f2u(a[1]), frame = f2u(a[2]);
             Sampler smp; smp.start(px, py, frame, 0);
             PathState ps; ps.ray = generate_ray(P, px, py, smp);
             smp.start(px, py, frame, 1);
             path_begin(ps);
-            for (int v = 0; v < 64; ++v) {
+            bool alive = live;
+            for (int v = 0; v < 64 && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
                 float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                bool end = path_bounce<true>(S, P, s_dyn_stack + threadIdx.x, ps, smp, cnt, dbg);
-                if (v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
-                if (end) break;
+                bool end = path_bounce<true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
+                if (end) alive = false;
             }
-            o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z;
+            if (live) { o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z; }
             break;
         }
         case 7: { // ray capture of one (pixel, frame) for the traversal replay: o[0] = vertex count, then 16 floats per
                   // vertex [closest ray o.xyz d.xyz t_max, 1 | shadow ray o.xyz d.xyz t_max, traced]; needs out_stride >= 1 + 16 * 24
-            extern __shared__ uint32_t s_dyn_stack[];
             const DScene S = *scene;
             uint32_t px = f2u(a[0]), py = f2u(a[1]), frame = f2u(a[2]);
             Sampler smp; smp.start(px, py, frame, 0);
@@ -636,19 +537,20 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             smp.start(px, py, frame, 1);
             path_begin(ps);
             int nv = 0;
-            for (int v = 0; v < 64; ++v) {
+            bool alive = live && P->max_depth > 0;
+            for (int v = 0; v < 64 && __any(alive); ++v) {
                 float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 Ray r = ps.ray;
-                bool end = path_bounce<true>(S, P, s_dyn_stack + threadIdx.x, ps, smp, cnt, dbg);
-                if (v < 24 && P->max_depth > 0) {
+                bool end = path_bounce<true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                if (alive && v < 24) {
                     float *q = o + 1 + v * 16;
                     q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = r.t_max; q[7] = 1.f;
                     for (int k = 0; k < 8; ++k) q[8 + k] = dbg[8 + k];
                     nv = v + 1;
                 }
-                if (end) break;
+                if (end) alive = false;
             }
-            o[0] = (float) nv;
+            if (live) o[0] = (float) nv;
             break;
         }
         default: break;
@@ -840,25 +742,28 @@ int vmk_build_accel(vmk_ctx *ctx) {
     const uint32_t n = ctx->n_tris;
     const int nb = (int) ((n + 255) / 256);
     DevBuf<uint64_t> keys, keys_sorted;
-    DevBuf<uint32_t> vals, vals_sorted;
-    DevBuf<int2> children, ranges;
-    DevBuf<int> parent_internal, parent_leaf, flags, depth;
-    DevBuf<float> leaf_box, node_box;
-    DevBuf<uint32_t> n_leaves;
-    DevBuf<uint8_t> temp;
-    auto cleanup = [&]() { keys.release(); keys_sorted.release(); vals.release(); vals_sorted.release(); children.release(); ranges.release(); parent_internal.release(); parent_leaf.release(); flags.release(); depth.release(); leaf_box.release(); node_box.release(); n_leaves.release(); temp.release(); };
+    DevBuf<uint32_t> vals, vals_sorted, n_leaves;
+    DevBuf<int> scalars; // [0] worst-case stack need, [1] BVH4 node counter, [2] next-level queue length
+    DevBuf<uint8_t> temp, scan_temp;
+    DevBuf<Box6> box; DevBuf<int> cl_a, cl_b, nn, pl_left, pl_right, pl_parent, pl_count;
+    DevBuf<unsigned long long> flags, scan;
+    DevBuf<vmk_tri_pos> pos_final; DevBuf<vmk_tri_attr> attr_final;
+    DevBuf<Bvh4Work> q_a, q_b;
+    auto cleanup = [&]() {
+        keys.release(); keys_sorted.release(); vals.release(); vals_sorted.release(); n_leaves.release(); scalars.release(); temp.release(); scan_temp.release();
+        box.release(); cl_a.release(); cl_b.release(); nn.release(); pl_left.release(); pl_right.release(); pl_parent.release(); pl_count.release();
+        flags.release(); scan.release(); pos_final.release(); attr_final.release(); q_a.release(); q_b.release();
+    };
 #define BUILD_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return VMK_ERR_HIP; } } while (0)
     BUILD_TRY(keys.alloc(n)); BUILD_TRY(keys_sorted.alloc(n)); BUILD_TRY(vals.alloc(n)); BUILD_TRY(vals_sorted.alloc(n));
     BUILD_TRY(ctx->tri_pos.alloc(n)); BUILD_TRY(ctx->tri_attr.alloc(n)); BUILD_TRY(ctx->tri_lookup.alloc(n));
-    size_t n_int = n > 1 ? n - 1 : 1;
-    BUILD_TRY(children.alloc(n_int)); BUILD_TRY(ranges.alloc(n_int)); BUILD_TRY(parent_internal.alloc(n_int)); BUILD_TRY(parent_leaf.alloc(n));
-    BUILD_TRY(flags.alloc(n_int)); BUILD_TRY(depth.alloc(1)); BUILD_TRY(leaf_box.alloc((size_t) n * 6)); BUILD_TRY(node_box.alloc(n_int * 6)); BUILD_TRY(n_leaves.alloc(1));
+    const size_t n_int = n > 1 ? n - 1 : 1; // a BVH4 has at most as many nodes as the binary tree has internal nodes
+    BUILD_TRY(scalars.alloc(3)); BUILD_TRY(n_leaves.alloc(1));
     BUILD_TRY(ctx->nodes.alloc(n_int));
-    BUILD_TRY(hipMemsetAsync(flags.p, 0, n_int * sizeof(int), st));
-    BUILD_TRY(hipMemsetAsync(depth.p, 0, sizeof(int), st));
+    BUILD_TRY(hipMemsetAsync(scalars.p, 0, 3 * sizeof(int), st));
     BUILD_TRY(hipMemsetAsync(n_leaves.p, 0, sizeof(uint32_t), st));
-    BUILD_TRY(hipMemsetAsync(ctx->nodes.p, 0, n_int * sizeof(BvhNode), st));
     BUILD_TRY(hipEventRecord(ctx->ev0, st));
+    // ---- 1. Morton order ----
     float ext[3];
     for (int k = 0; k < 3; ++k) { ext[k] = ctx->world_max[k] - ctx->world_min[k]; ext[k] = ext[k] > 0.f ? 1.f / ext[k] : 0.f; }
     hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, st, ctx->tri_pos_in.p, n, make_float3(ctx->world_min[0], ctx->world_min[1], ctx->world_min[2]), make_float3(ext[0], ext[1], ext[2]), keys.p, vals.p);
@@ -867,26 +772,20 @@ int vmk_build_accel(vmk_ctx *ctx) {
     BUILD_TRY(temp.alloc(temp_bytes ? temp_bytes : 16));
     BUILD_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys.p, keys_sorted.p, vals.p, vals_sorted.p, (int) n, 0, 63, st));
     hipLaunchKernelGGL(k_reorder, dim3(nb), dim3(256), 0, st, vals_sorted.p, n, ctx->tri_pos_in.p, ctx->tri_attr_in.p, ctx->tri_pos.p, ctx->tri_attr.p, ctx->tri_lookup.p);
-    int root_node = 0; // index into nodes[] of the root (internal) node
-    const char *mode_env = getenv("VMK_BVH");
-    const bool use_ploc = !(mode_env && std::string(mode_env) == "lbvh") && n > (uint32_t) kMaxLeafTris;
-    if (use_ploc) {
-        // ---- PLOC over the Morton-sorted triangles (ctx->tri_pos / tri_attr hold the sorted order here) ----
+    int h_scalars[3] = {0, 0, 0};
+    uint32_t h_leaves = 1, h_nodes = 0;
+    if (n > (uint32_t) kMaxLeafTris) {
+        // ---- 2. PLOC binary hierarchy over the Morton-sorted triangles (ctx->tri_pos / tri_attr hold the sorted order here) ----
         int radius = 16;
         if (const char *r = getenv("VMK_PLOC_RADIUS")) radius = std::max(1, std::min(256, atoi(r)));
-        DevBuf<Box6> box; DevBuf<int> cl_a, cl_b, nn, pl_left, pl_right, pl_parent, pl_count;
-        DevBuf<unsigned long long> flags, scan;
-        DevBuf<vmk_tri_pos> pos_final; DevBuf<vmk_tri_attr> attr_final;
-        DevBuf<uint8_t> scan_temp;
-        auto cleanup2 = [&]() { box.release(); cl_a.release(); cl_b.release(); nn.release(); pl_left.release(); pl_right.release(); pl_parent.release(); pl_count.release(); flags.release(); scan.release(); pos_final.release(); attr_final.release(); scan_temp.release(); };
-#define PLOC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup2(); cleanup(); return VMK_ERR_HIP; } } while (0)
         size_t n_all = 2 * (size_t) n;
-        PLOC_TRY(box.alloc(n_all)); PLOC_TRY(cl_a.alloc(n)); PLOC_TRY(cl_b.alloc(n)); PLOC_TRY(nn.alloc(n));
-        PLOC_TRY(pl_left.alloc(n_all)); PLOC_TRY(pl_right.alloc(n_all)); PLOC_TRY(pl_parent.alloc(n_all)); PLOC_TRY(pl_count.alloc(n_all));
-        PLOC_TRY(flags.alloc(n)); PLOC_TRY(scan.alloc(n)); PLOC_TRY(pos_final.alloc(n)); PLOC_TRY(attr_final.alloc(n));
+        BUILD_TRY(box.alloc(n_all)); BUILD_TRY(cl_a.alloc(n)); BUILD_TRY(cl_b.alloc(n)); BUILD_TRY(nn.alloc(n));
+        BUILD_TRY(pl_left.alloc(n_all)); BUILD_TRY(pl_right.alloc(n_all)); BUILD_TRY(pl_parent.alloc(n_all)); BUILD_TRY(pl_count.alloc(n_all));
+        BUILD_TRY(flags.alloc(n)); BUILD_TRY(scan.alloc(n)); BUILD_TRY(pos_final.alloc(n)); BUILD_TRY(attr_final.alloc(n));
+        BUILD_TRY(q_a.alloc(n_int)); BUILD_TRY(q_b.alloc(n_int));
         size_t scan_bytes = 0;
-        PLOC_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.p, scan.p, (int) n, st));
-        PLOC_TRY(scan_temp.alloc(scan_bytes ? scan_bytes : 16));
+        BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.p, scan.p, (int) n, st));
+        BUILD_TRY(scan_temp.alloc(scan_bytes ? scan_bytes : 16));
         hipLaunchKernelGGL(k_ploc_init, dim3(nb), dim3(256), 0, st, ctx->tri_pos.p, (int) n, box.p, cl_a.p, pl_parent.p, pl_count.p);
         int m = (int) n, node_base = (int) n, rounds = 0;
         int *cl_in = cl_a.p, *cl_out = cl_b.p;
@@ -896,11 +795,11 @@ int vmk_build_accel(vmk_ctx *ctx) {
             for (;;) {
                 if (!force) hipLaunchKernelGGL(k_ploc_nn, dim3(mb), dim3(256), 0, st, m, cl_in, box.p, radius, nn.p);
                 hipLaunchKernelGGL(k_ploc_flags, dim3(mb), dim3(256), 0, st, m, nn.p, flags.p, force);
-                PLOC_TRY(hipcub::DeviceScan::ExclusiveSum(scan_temp.p, scan_bytes, flags.p, scan.p, m, st));
+                BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(scan_temp.p, scan_bytes, flags.p, scan.p, m, st));
                 unsigned long long last_f = 0, last_s = 0;
-                PLOC_TRY(hipMemcpyAsync(&last_f, flags.p + (m - 1), 8, hipMemcpyDeviceToHost, st));
-                PLOC_TRY(hipMemcpyAsync(&last_s, scan.p + (m - 1), 8, hipMemcpyDeviceToHost, st));
-                PLOC_TRY(hipStreamSynchronize(st));
+                BUILD_TRY(hipMemcpyAsync(&last_f, flags.p + (m - 1), 8, hipMemcpyDeviceToHost, st));
+                BUILD_TRY(hipMemcpyAsync(&last_s, scan.p + (m - 1), 8, hipMemcpyDeviceToHost, st));
+                BUILD_TRY(hipStreamSynchronize(st));
                 unsigned long long tot = last_f + last_s;
                 int merges = (int) (tot >> 32), m_next = (int) (tot & 0xffffffffull);
                 if (merges == 0 && !force) { force = 1; continue; } // tie pathologies: pair neighbours (i, i^1) so every round makes progress
@@ -909,46 +808,50 @@ int vmk_build_accel(vmk_ctx *ctx) {
                 break;
             }
             std::swap(cl_in, cl_out);
-            if (++rounds > 4096) { ctx->error = "vmk_build_accel: PLOC did not converge"; cleanup2(); cleanup(); return VMK_ERR_STATE; }
+            if (++rounds > 4096) { ctx->error = "vmk_build_accel: PLOC did not converge"; cleanup(); return VMK_ERR_STATE; }
         }
-        if (node_base != (int) (2 * n - 1)) { ctx->error = "vmk_build_accel: PLOC node count mismatch"; cleanup2(); cleanup(); return VMK_ERR_STATE; }
-        root_node = (int) n - 2; // the last node created is the root: id 2n-2 -> index n-2
+        if (node_base != (int) (2 * n - 1)) { ctx->error = "vmk_build_accel: PLOC node count mismatch"; cleanup(); return VMK_ERR_STATE; }
+        // ---- 3. depth-first triangle order ----
         hipLaunchKernelGGL(k_ploc_place, dim3(nb), dim3(256), 0, st, (int) n, pl_left.p, pl_right.p, pl_parent.p, pl_count.p, vals_sorted.p,
-                           ctx->tri_pos.p, ctx->tri_attr.p, pos_final.p, attr_final.p, ctx->tri_lookup.p, depth.p);
-        hipLaunchKernelGGL(k_ploc_emit, dim3(nb), dim3(256), 0, st, (int) n, box.p, pl_left.p, pl_right.p, pl_parent.p, pl_count.p, ctx->nodes.p, n_leaves.p);
-        PLOC_TRY(hipMemcpyAsync(ctx->tri_pos.p, pos_final.p, (size_t) n * sizeof(vmk_tri_pos), hipMemcpyDeviceToDevice, st));
-        PLOC_TRY(hipMemcpyAsync(ctx->tri_attr.p, attr_final.p, (size_t) n * sizeof(vmk_tri_attr), hipMemcpyDeviceToDevice, st));
-        PLOC_TRY(hipStreamSynchronize(st));
-        cleanup2();
-#undef PLOC_TRY
-    } else {
-    if (n > 1) hipLaunchKernelGGL(k_karras, dim3(nb), dim3(256), 0, st, keys_sorted.p, (int) n, children.p, ranges.p, parent_internal.p, parent_leaf.p);
-    hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, ctx->tri_pos.p, (int) n, children.p, parent_internal.p, parent_leaf.p, leaf_box.p, node_box.p, flags.p);
-    if (n > 1) {
-        hipLaunchKernelGGL(k_depth, dim3(nb), dim3(256), 0, st, (int) n, parent_internal.p, parent_leaf.p, ranges.p, depth.p);
-        hipLaunchKernelGGL(k_emit, dim3(nb), dim3(256), 0, st, (int) n, children.p, ranges.p, leaf_box.p, node_box.p, ctx->nodes.p, n_leaves.p);
-    }
+                           ctx->tri_pos.p, ctx->tri_attr.p, pos_final.p, attr_final.p, ctx->tri_lookup.p);
+        BUILD_TRY(hipMemcpyAsync(ctx->tri_pos.p, pos_final.p, (size_t) n * sizeof(vmk_tri_pos), hipMemcpyDeviceToDevice, st));
+        BUILD_TRY(hipMemcpyAsync(ctx->tri_attr.p, attr_final.p, (size_t) n * sizeof(vmk_tri_attr), hipMemcpyDeviceToDevice, st));
+        // ---- 4. collapse to 128 B BVH4 nodes, level by level from the root (binary id 2n-2 -> node 0) ----
+        Bvh4Work root_work = {(int) (2 * n - 2), 0, 0, 0};
+        int one = 1;
+        BUILD_TRY(hipMemcpyAsync(q_a.p, &root_work, sizeof(root_work), hipMemcpyHostToDevice, st));
+        BUILD_TRY(hipMemcpyAsync(scalars.p + 1, &one, sizeof(int), hipMemcpyHostToDevice, st));
+        Bvh4Work *q_in = q_a.p, *q_out = q_b.p;
+        int n_in = 1, levels = 0;
+        while (n_in > 0) {
+            BUILD_TRY(hipMemsetAsync(scalars.p + 2, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_bvh4_level, dim3((n_in + 255) / 256), dim3(256), 0, st, q_in, n_in, q_out, scalars.p + 2, scalars.p + 1, box.p,
+                               pl_left.p, pl_right.p, pl_count.p, ctx->nodes.p, n_leaves.p, scalars.p);
+            BUILD_TRY(hipMemcpyAsync(&n_in, scalars.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+            BUILD_TRY(hipStreamSynchronize(st));
+            std::swap(q_in, q_out);
+            if (++levels > 4096) { ctx->error = "vmk_build_accel: BVH4 collapse did not terminate"; cleanup(); return VMK_ERR_STATE; }
+        }
+        BUILD_TRY(hipMemcpyAsync(h_scalars, scalars.p, sizeof(h_scalars), hipMemcpyDeviceToHost, st));
+        BUILD_TRY(hipMemcpyAsync(&h_leaves, n_leaves.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        BUILD_TRY(hipStreamSynchronize(st));
+        h_nodes = (uint32_t) h_scalars[1];
     }
     BUILD_TRY(hipEventRecord(ctx->ev1, st));
-    BUILD_TRY(hipGetLastError());
-    int h_depth = 0; uint32_t h_leaves = 0;
-    BUILD_TRY(hipMemcpyAsync(&h_depth, depth.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    BUILD_TRY(hipMemcpyAsync(&h_leaves, n_leaves.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     BUILD_TRY(hipStreamSynchronize(st));
     float ms = 0.f; (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     cleanup();
 #undef BUILD_TRY
-#ifndef VMK_EXPERIMENT_NO_DEPTH_CHECK // tuning builds only: a too-shallow stack silently drops subtrees
-    if (h_depth + 2 > kStackDepth) { ctx->error = "vmk_build_accel: BVH depth " + std::to_string(h_depth) + " exceeds the LDS traversal stack (" + std::to_string(kStackDepth) + ")"; return VMK_ERR_UNSUPPORTED; }
-#endif
+    if (h_nodes > n_int) { ctx->error = "vmk_build_accel: BVH4 node count exceeds the allocation"; return VMK_ERR_STATE; }
+    if (h_scalars[0] > kQuadStack) { ctx->error = "vmk_build_accel: worst-case traversal stack need " + std::to_string(h_scalars[0]) + " exceeds the per-ray LDS stack (" + std::to_string(kQuadStack) + ")"; return VMK_ERR_UNSUPPORTED; }
     DScene &h = ctx->h_scene;
     h.tri_pos = ctx->tri_pos.p; h.tri_attr = ctx->tri_attr.p; h.tri_lookup = ctx->tri_lookup.p; h.nodes = ctx->nodes.p;
-    h.root = n <= (uint32_t) kMaxLeafTris ? (int32_t) ~((uint32_t) 0 | ((n - 1u) << 28)) : root_node;
+    h.root = n <= (uint32_t) kMaxLeafTris ? (int32_t) ~((uint32_t) 0 | ((n - 1u) << 28)) : 0;
     HIP_TRY(ctx->d_scene.upload(&h, 1, st));
     HIP_TRY(hipStreamSynchronize(st));
     ctx->tri_pos_in.release(); ctx->tri_attr_in.release();
     ctx->scene_ready = false; // host copies consumed; a new upload is needed before rebuilding
-    ctx->accel = {(uint32_t) (n > 1 ? n - 1 : 0), n <= (uint32_t) kMaxLeafTris ? 1u : h_leaves, (uint32_t) sizeof(BvhNode), (uint32_t) sizeof(vmk_tri_pos), ms, (uint32_t) h_depth, (uint32_t) kStackDepth};
+    ctx->accel = {h_nodes, h_leaves, (uint32_t) sizeof(BvhNode), (uint32_t) sizeof(vmk_tri_pos), ms, (uint32_t) h_scalars[0], (uint32_t) kQuadStack};
     ctx->accel_ready = true;
     return VMK_OK;
 }
@@ -1101,14 +1004,8 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     if (repeats == 0) repeats = 1;
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipEventRecord(ctx->ev0, ctx->stream);
-    int dyn = 0;
-    if (const char *v = getenv("VMK_TRACE_DYN")) dyn = atoi(v);
-    for (uint32_t r = 0; r < repeats; ++r) {
-        if (dyn > 0) {
-            (void) hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream);
-            hipLaunchKernelGGL(k_trace_dyn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, dyn);
-        } else hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p);
-    }
+    for (uint32_t r = 0; r < repeats; ++r)
+        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p);
     (void) hipEventRecord(ctx->ev1, ctx->stream);
     e = hipMemcpyAsync(hit_out, h.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1138,7 +1035,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     if (e == hipSuccess) e = dout.alloc((size_t) n * out_stride);
     if (e == hipSuccess) e = hipMemsetAsync(dout.p, 0, (size_t) n * out_stride * 4, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_test, dim3((n + 63) / 64), dim3(64), kStackDepth * kBlock * sizeof(uint32_t), ctx->stream, ctx->d_scene.p, ctx->d_params.p, kind, n, di.p, in_stride, dout.p, out_stride);
+        hipLaunchKernelGGL(k_test, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_scene.p, ctx->d_params.p, kind, n, di.p, in_stride, dout.p, out_stride);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, (size_t) n * out_stride * 4, hipMemcpyDeviceToHost, ctx->stream);
