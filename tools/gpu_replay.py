@@ -20,18 +20,20 @@ def tile_pixels(width, height, tile, step):
     return np.concatenate(out).astype(np.uint32)
 
 
-def replay(pipe, step=16, frame=0, repeats=5):
+def replay(pipe, step=16, frame=0, repeats=5, tile_x=4):
     be, p = pipe.backend, pipe.params
     pix = tile_pixels(p.width, p.height, 32, step)
     rays = be.capture_rays(pix, frame)
     res = {"paths": int(pix.shape[0]), "rays": int(rays["kind"].shape[0])}
     for name, kind in (("closest", 0), ("shadow", 1)):
         m = rays["kind"] == kind
-        n = int(m.sum())
-        if n == 0:
+        if int(m.sum()) == 0:
             continue
+        # the capture is tiled `tile_x` times so that one launch fills the chip (>= 3 M rays), order within a copy kept
+        o, d, t = (np.tile(rays[k][m], (tile_x,) + (1,) * (rays[k].ndim - 1)) for k in ("org", "dir", "tmax"))
+        n = int(t.shape[0])
         be.reset_counters()
-        _, ms = be.trace(rays["org"][m], rays["dir"][m], rays["tmax"][m], any_hit=bool(kind), repeats=repeats)
+        _, ms = be.trace(o, d, t, any_hit=bool(kind), repeats=repeats)
         c = be.counters()
         traced = c["closest_rays"] + c["shadow_rays"]
         b = (c["nodes_visited"] * 128 + c["tris_tested"] * 48 + traced * 44) / repeats

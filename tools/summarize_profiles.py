@@ -17,13 +17,13 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for r in stats[:12]:
         f.write(",".join([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]) + "\n")
-kr = [r for r in stats if r["Name"].startswith("k_render")][0]
+kr = max((r for r in stats if "k_render" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 
 def pmc(name):
     f = glob.glob(os.path.join(prof, name, "*", "*_counter_collection.csv"))
     if not f:
         return {}, {}
-    rows = [r for r in csv.DictReader(open(f[0])) if r["Kernel_Name"].startswith("k_render")]
+    rows = [r for r in csv.DictReader(open(f[0])) if "k_render" in r["Kernel_Name"]]
     agg = collections.defaultdict(float)
     for r in rows:
         agg[r["Counter_Name"]] += float(r["Counter_Value"])

@@ -74,6 +74,61 @@ VD void wave_lds_fence() { // LDS written by other lanes of this wave is visible
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- where the rays come from and where the hits go ----------------------------------------------------------
+// Megakernel: every lane stages its own ray in LDS, the quads work through the compacted list of staged lanes.
+struct LdsRayIO {
+    WaveScratch *ws;
+    uint32_t n, next; // wave-uniform
+    VD bool more() const { return next < n; }
+    VD uint32_t claim(uint32_t count) { uint32_t b = next; next = min(next + count, n); return b; }
+    VD bool load(uint32_t idx, int &owner, V3 &o, V3 &d, float &t_max, bool &anyh) {
+        if (idx >= n) return false;
+        owner = (int) ws->list[idx];
+        float4 a = ws->ray[owner][0], b = ws->ray[owner][1];
+        o = mk3(a.x, a.y, a.z); t_max = a.w; d = mk3(b.x, b.y, b.z); anyh = b.w != 0.f;
+        return true;
+    }
+    VD void store(int owner, bool found, uint32_t inst, uint32_t prim, uint32_t tri, float u, float v) { // one lane per ray
+        ws->ray[owner][0] = make_float4(u2f(inst), u2f(prim), u2f(tri), found ? 1.f : 0.f);
+        ws->ray[owner][1] = make_float4(u, v, 0.f, 0.f);
+    }
+};
+// Replay kernel: SoA ray planes in HBM shared by the whole grid.  A wave takes `chunk` rays from the pool with one atomic
+// (a claim per refill batch serialises on the one counter: 2 M rays took 4.3 ms instead of 0.8) and hands them to its
+// quads as they fall idle, so every quad stays busy until the pool is empty (no per-64-ray tail).
+struct GlobalRayIO {
+    uint32_t chunk; // rays per claim: large enough to keep the counter cold, small enough to balance the waves
+    const float *org, *dir, *tmax;
+    uint32_t n;
+    uint32_t *queue;
+    uint4 *hit_out;
+    bool any_hit;
+    uint32_t lo, hi; // wave-uniform: unclaimed part of the wave's current chunk
+    bool exhausted;  // wave-uniform: the pool has no further chunk
+    VD bool more() const { return lo < hi || !exhausted; }
+    VD uint32_t claim(uint32_t count) { // called in wave-uniform control flow; rays [base, lo) are handed out
+        if (lo >= hi) {
+            uint32_t b = 0;
+            if ((threadIdx.x & 63u) == 0) b = atomicAdd(queue, chunk);
+            b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+            lo = min(b, n); hi = min(b + chunk, n);
+            if (b + chunk >= n) exhausted = true;
+        }
+        uint32_t base = lo;
+        lo = min(lo + count, hi);
+        return base;
+    }
+    VD bool load(uint32_t idx, int &owner, V3 &o, V3 &d, float &t_max, bool &anyh) {
+        if (idx >= lo) return false; // beyond what this claim handed out: the quad asks again in the next batch
+        owner = (int) idx;
+        o = mk3(org[idx], org[n + idx], org[2 * n + idx]); d = mk3(dir[idx], dir[n + idx], dir[2 * n + idx]); t_max = tmax[idx]; anyh = any_hit;
+        return true;
+    }
+    VD void store(int owner, bool found, uint32_t inst, uint32_t prim, uint32_t tri, float u, float v) {
+        hit_out[owner] = any_hit ? make_uint4(found ? 1u : 0u, 0, 0, 0) : make_uint4(inst, prim, f2u(u), f2u(v));
+    }
+};
+
 #ifndef VMK_NODE_QUADS_MIN
 #define VMK_NODE_QUADS_MIN 8 // leave the node phase when fewer quads than this are on internal nodes and others wait
 #endif
@@ -81,35 +136,22 @@ VD void wave_lds_fence() { // LDS written by other lanes of this wave is visible
 #define VMK_REFILL_QUADS_MIN 4 // hand back hits / take new rays once this many quads are idle (or nothing else is left)
 #endif
 
-// Trace the rays of all lanes of the wave.  EVERY lane of the wave must call this (convergently); `active` says whether
-// the lane has a ray.  any_hit rays stop at the first valid hit (occlusion query), the others return the closest hit.
-// Returns found; `hit` is filled for closest-hit rays.
+// The traversal loop of one wave; EVERY lane of the wave must be here (convergently).
 //
 // Loop structure ("while-while" with one postponed leaf per ray): the wave alternates between a node phase, in which
 // every quad that sits on an internal node takes steps, and a leaf phase.  A quad that reaches a leaf parks it in
 // `pend` and keeps descending with the next stack entry, so the node phase only loses a quad when it holds two leaves;
 // the price is that the parked leaf cannot tighten best_t for the nodes visited meanwhile.  Hits are handed back and new
 // rays taken in batches (VMK_REFILL_QUADS_MIN) because that block costs as much as a node step for the whole wave.
-VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, WaveScratch *ws, Hit &hit, DCounters &cnt) {
+// Returns the number of rays this quad-lane started (lane q == 0 only) in *n_rays for the callers' counters.
+template<class IO>
+VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, uint32_t *n_rays) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
-    hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
-    if (S.n_tris == 0) return false;
-    // ---- stage the rays of the active lanes ----
-    const unsigned long long act_mask = __ballot(active);
-    const uint32_t n_act = (uint32_t) __popcll(act_mask);
-    if (n_act == 0) return false;
-    if (active) {
-        ws->ray[lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.t_max);
-        ws->ray[lane][1] = make_float4(r.d.x, r.d.y, r.d.z, any_hit ? 1.f : 0.f);
-        ws->list[__popcll(act_mask & ((1ull << lane) - 1ull))] = lane;
-    }
-    wave_lds_fence();
     // ---- per-quad traversal state, replicated in the quad's 4 lanes ----
     int32_t cur = kTravDone;         // internal node (0 <= cur < kEmptyRef), leaf (< 0) or kTravDone
     int32_t pend = kTravDone;        // parked leaf or kTravDone
     int sp = 0;
     int owner = -1;
-    uint32_t next = 0;               // wave-uniform: next unclaimed entry of ws->list
     V3 o = mk3(0.f), d = mk3(0.f), inv = mk3(0.f);
     float t_max = 0.f, best_t = 0.f; // best_t: quad-wide culling bound
     bool anyh = false;
@@ -117,7 +159,7 @@ VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, 
     float bt = 0.f, bu = 0.f, bv = 0.f;
     uint32_t binst = VMK_INVALID, bprim = VMK_INVALID, btri = VMK_INVALID;
     bool found = false;
-    uint32_t nn = 0, nt = 0;
+    uint32_t nn = 0, nt = 0, nr = 0;
     // lane-constant tie-break bits for the child ordering: does quad lane (q ^ k) come before me?
     const bool before1 = (q ^ 1u) < q, before2 = (q ^ 2u) < q, before3 = (q ^ 3u) < q;
 #define VMK_POP() do { if (sp > 0) { --sp; cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
@@ -129,7 +171,7 @@ VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, 
             const unsigned long long nmask = __ballot(at_node);
             if (nmask == 0) break;
             if (!first && __popcll(nmask) < 4 * VMK_NODE_QUADS_MIN) {
-                const bool waiting = !at_node && (pend != kTravDone || cur < 0 || owner >= 0 || next < n_act);
+                const bool waiting = !at_node && (pend != kTravDone || cur < 0 || owner >= 0 || io.more());
                 if (__any(waiting)) break;
             }
             if (at_node) { // lane q tests child q
@@ -137,6 +179,8 @@ VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, 
                 float4 a = p[0], b = p[1];
                 int32_t ref = (int32_t) f2u(b.z);
                 float tn;
+                // (unused slots hold a far-away point box; the explicit ref test keeps NaN rays, whose slab test passes
+                // everywhere, from walking into them)
                 bool h = hit_box(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, o, inv, best_t, &tn) && ref != kEmptyRef;
                 nn += q == 0 ? 1u : 0u;
                 float t = h ? tn : __builtin_inff(); // misses are never ranked before a hit
@@ -180,44 +224,67 @@ VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, 
         if (cur < 0) { pend = cur; VMK_POP(); } // a second leaf was waiting: park it for the next leaf phase
         // ================= hand back hits, take new rays =================
         const bool idle = cur == kTravDone && pend == kTravDone;
-        const bool want = idle && (owner >= 0 || next < n_act);
+        const bool want = idle && (owner >= 0 || io.more());
         const unsigned long long want_mask = __ballot(want);
         const bool any_busy = __any(!idle);
         if (want_mask == 0) { if (!any_busy) break; continue; }
         if (any_busy && __popcll(want_mask) < 4 * VMK_REFILL_QUADS_MIN) continue;
-        if (idle && owner >= 0) { // ---- retire: merge the 4 lane-local candidates, lane 0 returns the hit ----
-#define VMK_QUAD_MERGE(CTRL) { \
-            int32_t of = quad_perm_i<CTRL>(found ? 1 : 0); float ot = quad_perm_f<CTRL>(bt); \
-            uint32_t oi = (uint32_t) quad_perm_i<CTRL>((int32_t) binst), op = (uint32_t) quad_perm_i<CTRL>((int32_t) bprim), otr = (uint32_t) quad_perm_i<CTRL>((int32_t) btri); \
-            float ou = quad_perm_f<CTRL>(bu), ov = quad_perm_f<CTRL>(bv); \
-            bool take = of && (!found || ot < bt || (ot == bt && (oi < binst || (oi == binst && op < bprim)))); \
-            if (take) { found = true; bt = ot; binst = oi; bprim = op; btri = otr; bu = ou; bv = ov; } }
-            VMK_QUAD_MERGE(kQuadXor1)
-            VMK_QUAD_MERGE(kQuadXor2)
-#undef VMK_QUAD_MERGE
-            if (q == 0) {
-                ws->ray[owner][0] = make_float4(u2f(binst), u2f(bprim), u2f(btri), found ? 1.f : 0.f);
-                ws->ray[owner][1] = make_float4(bu, bv, 0.f, 0.f);
-            }
+        if (idle && owner >= 0) {
+            // ---- retire: the lane that holds the quad's best candidate (min t, then inst, then prim) returns it ----
+            float m = found ? bt : __builtin_inff();
+            m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
+            m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
+            const bool c1 = found && bt == m;
+            uint32_t ki = c1 ? binst : 0xffffffffu;
+            ki = min(ki, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) ki));
+            ki = min(ki, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) ki));
+            const bool c2 = c1 && binst == ki;
+            uint32_t kp = c2 ? bprim : 0xffffffffu;
+            kp = min(kp, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) kp));
+            kp = min(kp, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) kp));
+            const bool none = !(m < __builtin_inff());
+            if (c2 && bprim == kp) io.store(owner, true, binst, bprim, btri, bu, bv);
+            else if (none && q == 0) io.store(owner, false, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f);
             owner = -1;
         }
+        // ---- refill ----
         const unsigned long long idle_mask = __ballot(idle && q == 0);
-        if (idle) { // ---- refill from the list ----
-            uint32_t idx = next + (uint32_t) __popcll(idle_mask & ((1ull << (lane & ~3u)) - 1ull));
-            if (idx < n_act) {
-                owner = (int) ws->list[idx];
-                float4 a = ws->ray[owner][0], b = ws->ray[owner][1];
-                o = mk3(a.x, a.y, a.z); t_max = a.w; d = mk3(b.x, b.y, b.z); anyh = b.w != 0.f;
+        const uint32_t base = io.more() ? io.claim((uint32_t) __popcll(idle_mask)) : 0xffffffffu;
+        if (idle && base != 0xffffffffu) {
+            uint32_t idx = base + (uint32_t) __popcll(idle_mask & ((1ull << (lane & ~3u)) - 1ull));
+            if (io.load(idx, owner, o, d, t_max, anyh)) {
                 // v_rcp_f32 (1 ulp) is enough here: inv only feeds the padded, conservative slab test
                 inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
                 best_t = t_max; cur = S.root; sp = 0;
                 found = false; bt = t_max; binst = VMK_INVALID; bprim = VMK_INVALID; btri = VMK_INVALID; bu = 0.f; bv = 0.f;
+                nr += q == 0 ? 1u : 0u;
             }
         }
-        next = min(next + (uint32_t) __popcll(idle_mask), n_act);
     }
 #undef VMK_POP
     cnt.nodes += nn; cnt.tris += nt;
+    if (n_rays) *n_rays = nr;
+}
+
+// Trace the rays of all lanes of the wave.  EVERY lane of the wave must call this (convergently); `active` says whether
+// the lane has a ray.  any_hit rays stop at the first valid hit (occlusion query), the others return the closest hit.
+// Returns found; `hit` is filled for closest-hit rays.
+VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, WaveScratch *ws, Hit &hit, DCounters &cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
+    if (S.n_tris == 0) return false;
+    // ---- stage the rays of the active lanes ----
+    const unsigned long long act_mask = __ballot(active);
+    const uint32_t n_act = (uint32_t) __popcll(act_mask);
+    if (n_act == 0) return false;
+    if (active) {
+        ws->ray[lane][0] = make_float4(r.o.x, r.o.y, r.o.z, r.t_max);
+        ws->ray[lane][1] = make_float4(r.d.x, r.d.y, r.d.z, any_hit ? 1.f : 0.f);
+        ws->list[__popcll(act_mask & ((1ull << lane) - 1ull))] = lane;
+    }
+    wave_lds_fence();
+    LdsRayIO io = {ws, n_act, 0};
+    traverse_core(S, io, ws, cnt, nullptr);
     wave_lds_fence();
     bool res = false;
     if (active) {

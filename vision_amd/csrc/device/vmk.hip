@@ -31,7 +31,8 @@ using namespace vmkd;
 
 constexpr int kBlock = 256;
 #ifndef VMK_WAVES_PER_SIMD
-#define VMK_WAVES_PER_SIMD 4 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane); measured 1:306 2:533 3:652 4:714 Mrays/s on classroom (profiles/r01_tuning.md)
+#define VMK_WAVES_PER_SIMD 5 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane); measured on classroom with the
+                             // quad traversal: 3: 2015, 4: 2206, 5: 2297, 6: 1825, 8: 1487 Mrays/s
 #endif
 constexpr int kDefaultTile = 32;
 
@@ -192,7 +193,7 @@ __global__ void k_bvh4_level(const Bvh4Work *in, int n_in, Bvh4Work *out_q, int 
     for (int k = 0; k < 4; ++k) {
         BvhChild &ch = nd.child[k];
         ch.pad = 0;
-        if (k >= ns) { ch.x[0] = ch.y[0] = ch.z[0] = 0.f; ch.x[1] = ch.y[1] = ch.z[1] = 0.f; ch.ref = kEmptyRef; continue; }
+        if (k >= ns) { ch.x[0] = ch.y[0] = ch.z[0] = 3.0e38f; ch.x[1] = ch.y[1] = ch.z[1] = 3.0e38f; ch.ref = kEmptyRef; continue; } // unused slot: a point no ray reaches
         Box6 b = box[slot[k]];
         ch.x[0] = b.lo[0]; ch.x[1] = b.hi[0]; ch.y[0] = b.lo[1]; ch.y[1] = b.hi[1]; ch.z[0] = b.lo[2]; ch.z[1] = b.hi[2];
         int c = count[slot[k]];
@@ -415,24 +416,18 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
 // traversal replay, tone map, unit tests
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_trace(const DScene *scene, uint32_t n, const float *org, const float *dir, const float *tmax,
-                                                  int any_hit, uint32_t *hit_out, unsigned long long *counters) {
+                                                  int any_hit, uint32_t *hit_out, unsigned long long *counters, uint32_t *queue, uint32_t chunk) {
     __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = *scene;
     WaveScratch *ws = s_ws + (threadIdx.x >> 6);
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) { // block-uniform trip count
-        uint32_t i = base + threadIdx.x;
-        bool active = i < n;
-        Ray r = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
-        // SoA rays: component arrays of length n (coalesced 4 B/lane loads)
-        if (active) r = {mk3(org[i], org[n + i], org[2 * n + i]), mk3(dir[i], dir[n + i], dir[2 * n + i]), tmax[i]};
-        Hit h;
-        bool found = traverse_wave(S, r, active, any_hit != 0, ws, h, cnt);
-        if (active) {
-            if (any_hit) { cnt.shadow++; reinterpret_cast<uint4 *>(hit_out)[i] = make_uint4(found ? 1u : 0u, 0, 0, 0); }
-            else { cnt.closest++; reinterpret_cast<uint4 *>(hit_out)[i] = make_uint4(h.inst, h.prim, f2u(h.bary.x), f2u(h.bary.y)); }
-        }
-    }
+    // persistent waves: the quads of every wave pull rays from one pool (SoA planes, 4 B/lane loads) until it is empty
+    GlobalRayIO io = {chunk, org, dir, tmax, n, queue, reinterpret_cast<uint4 *>(hit_out), any_hit != 0, 0, 0, false};
+    uint32_t n_rays = 0;
+    if (S.n_tris == 0) { // nothing to hit
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { io.store((int) i, false, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); ++n_rays; }
+    } else traverse_core(S, io, ws, cnt, &n_rays);
+    if (any_hit) cnt.shadow += n_rays; else cnt.closest += n_rays;
     uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
     for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
 }
@@ -776,8 +771,8 @@ int vmk_build_accel(vmk_ctx *ctx) {
     uint32_t h_leaves = 1, h_nodes = 0;
     if (n > (uint32_t) kMaxLeafTris) {
         // ---- 2. PLOC binary hierarchy over the Morton-sorted triangles (ctx->tri_pos / tri_attr hold the sorted order here) ----
-        int radius = 16;
-        if (const char *r = getenv("VMK_PLOC_RADIUS")) radius = std::max(1, std::min(256, atoi(r)));
+        int radius = 128; // classroom: 14.6 node visits per ray at radius 16, 13.1 at 128 (+6 % Mrays/s) for 4 ms more build time
+        if (const char *r = getenv("VMK_PLOC_RADIUS")) radius = std::max(1, std::min(1024, atoi(r)));
         size_t n_all = 2 * (size_t) n;
         BUILD_TRY(box.alloc(n_all)); BUILD_TRY(cl_a.alloc(n)); BUILD_TRY(cl_b.alloc(n)); BUILD_TRY(nn.alloc(n));
         BUILD_TRY(pl_left.alloc(n_all)); BUILD_TRY(pl_right.alloc(n_all)); BUILD_TRY(pl_parent.alloc(n_all)); BUILD_TRY(pl_count.alloc(n_all));
@@ -1000,12 +995,16 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     hipError_t e;
     if ((e = o.upload(so.data(), so.size(), ctx->stream)) != hipSuccess || (e = d.upload(sd.data(), sd.size(), ctx->stream)) != hipSuccess ||
         (e = t.upload(tmax, n, ctx->stream)) != hipSuccess || (e = h.alloc((size_t) n * 4)) != hipSuccess) { ctx->error = std::string("vmk_trace_rays: ") + hipGetErrorString(e); cleanup(); return VMK_ERR_HIP; }
-    uint32_t grid = (uint32_t) std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * 8);
+    uint32_t grid = (uint32_t) std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * 6); // persistent waves, 6 blocks per CU fit (LDS)
+    uint32_t chunk = (uint32_t) (n / ((uint64_t) grid * (kBlock / 64) * 2)) & ~15u; // about two claims per wave
+    chunk = std::max(16u, std::min(256u, chunk));
     if (repeats == 0) repeats = 1;
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipEventRecord(ctx->ev0, ctx->stream);
-    for (uint32_t r = 0; r < repeats; ++r)
-        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p);
+    for (uint32_t r = 0; r < repeats; ++r) {
+        (void) hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream);
+        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
+    }
     (void) hipEventRecord(ctx->ev1, ctx->stream);
     e = hipMemcpyAsync(hit_out, h.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
