@@ -252,7 +252,10 @@ int vmk_reset_accum(vmk_ctx *ctx);
 
 /* Render frames [frame_begin, frame_begin+frame_count) of the owned tiles, fused with accumulation:
  * acc = lerp(1/(f+1), acc, L_f) per frame f in order (frame_buffer.cpp:117-126).  Asynchronous on the
- * ctx stream; kernel_ms (optional) receives the HIP-event time of the launch and forces a sync. */
+ * ctx stream; kernel_ms (optional) receives the HIP-event time of the launch(es) and forces a sync.
+ * Internally one work item is one path (pixel, frame): paths write radiance to per-frame staging planes
+ * (frame_count x owned pixels x 16 B of device memory, at most 8 GiB per launch — larger batches are split)
+ * and a resolve kernel folds the planes into the accumulation buffer in frame order. */
 int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, const vmk_tiles *tiles,
                      float *kernel_ms);
 int vmk_synchronize(vmk_ctx *ctx);

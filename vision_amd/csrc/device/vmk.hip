@@ -309,14 +309,22 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
 // ---------------------------------------------------------------------------------------------------------
 // the megakernel
 // ---------------------------------------------------------------------------------------------------------
+// Work decomposition of one render launch.  A work item is ONE path: item w -> frame frame_begin + w / n_slots of pixel
+// slot w % n_slots (slot = owned tile k, Morton position inside the tile), so consecutive items are neighbouring pixels
+// of the same frame.  Paths write their radiance to the staging plane stage[frame][slot]; k_film_resolve then folds the
+// planes into the accumulation buffer in frame order (the film's running mean is order dependent).  Path-granular
+// items keep every lane busy to the end of the launch however few pixels a GPU owns (1/8 of the image at 8 GPUs is
+// fewer pixels than resident lanes) and whatever the cost spread between pixels.
 struct RenderArgs {
     const DScene *scene;
     const vmk_render_params *params;
     float4 *accum;
+    float4 *stage;        // [frame_count][n_slots]
     uint32_t *queue;      // work-item counter
     unsigned long long *counters; // 7 x u64 (vmk_counters layout)
     uint32_t frame_begin, frame_count;
-    uint32_t tile_size, tile_shift, tiles_x, tiles_y, rank, world, n_work;
+    uint32_t tile_size, tile_shift, tiles_x, tiles_y, rank, world;
+    uint32_t n_slots, n_items, chunk; // chunk: items a wave claims with one atomic
 };
 
 __device__ __forceinline__ uint32_t compact_bits(uint32_t v) { // inverse of 2-D Morton interleave (even bits)
@@ -329,6 +337,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ bool slot_to_pixel(const RenderArgs &A, uint32_t slot, uint32_t width, uint32_t height, uint32_t *px, uint32_t *py) {
+    uint32_t k = slot >> (2u * A.tile_shift), r = slot & (A.tile_size * A.tile_size - 1u);
+    uint32_t tile = A.rank + k * A.world;
+    uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+    *px = tx * A.tile_size + compact_bits(r); *py = ty * A.tile_size + compact_bits(r >> 1);
+    return *px < width && *py < height;
+}
+
 template<bool FULL>
 __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
@@ -338,69 +354,54 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
     WaveScratch *ws = s_ws + (threadIdx.x >> 6);
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
 
-    const uint32_t frame_end = A.frame_begin + A.frame_count;
-
+    // wave-uniform: the part of the wave's claimed chunk not yet handed to a lane
+    uint32_t w_lo = 0, w_hi = 0;
+    bool exhausted = false;
     // per-lane persistent state
-    bool has_pixel = false, queue_empty = false, path_alive = false;
-    uint32_t px = 0, py = 0, frame = 0;
-    V4 acc = {0.f, 0.f, 0.f, 0.f};
+    bool has_path = false;
+    uint32_t item = 0;
     Sampler sampler; sampler.state = 0;
     PathState ps;
     ps.ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
     ps.L = mk3(0.f); ps.T = mk3(1.f); ps.prev_ng = mk3(0.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.bounces = 0;
 
     for (;;) {
-        // ---- refill idle lanes with new pixels (wavefront ballot + one atomic per wave) ----
-        bool need = !has_pixel && !queue_empty;
-        unsigned long long need_mask = __ballot(need);
-        if (need_mask) {
-            uint32_t n_need = (uint32_t) __popcll(need_mask);
-            uint32_t base = 0;
-            int leader = __ffsll((long long) need_mask) - 1;
-            if ((int) lane == leader) base = atomicAdd(A.queue, n_need);
-            base = __shfl(base, leader, 64);
-            if (need) {
-                uint32_t w = base + (uint32_t) __popcll(need_mask & ((1ull << lane) - 1ull));
-                if (w >= A.n_work) queue_empty = true;
-                else {
-                    uint32_t per_tile = A.tile_size * A.tile_size;
-                    uint32_t k = w >> (2u * A.tile_shift), r = w & (per_tile - 1u);
-                    uint32_t tile = A.rank + k * A.world;
-                    uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
-                    px = tx * A.tile_size + compact_bits(r); py = ty * A.tile_size + compact_bits(r >> 1);
-                    if (px < P->width && py < P->height) {
-                        has_pixel = true; frame = A.frame_begin; path_alive = false;
-                        float4 a = A.accum[(size_t) py * P->width + px];
-                        acc = {a.x, a.y, a.z, a.w};
+        // ---- hand new paths to idle lanes: ballot + prefix inside the wave, one atomic per chunk ----
+        const unsigned long long need_mask = __ballot(!has_path);
+        if (need_mask && (w_lo < w_hi || !exhausted)) {
+            if (w_lo >= w_hi) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(A.queue, A.chunk);
+                b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+                w_lo = min(b, A.n_items); w_hi = (uint32_t) min((unsigned long long) b + A.chunk, (unsigned long long) A.n_items);
+                if ((unsigned long long) b + A.chunk >= A.n_items) exhausted = true;
+            }
+            if (!has_path) {
+                uint32_t w = w_lo + (uint32_t) __popcll(need_mask & ((1ull << lane) - 1ull));
+                if (w < w_hi) {
+                    uint32_t f = w / A.n_slots, slot = w - f * A.n_slots, px, py;
+                    if (slot_to_pixel(A, slot, P->width, P->height, &px, &py)) {
+                        // ray generation (rt_geom kernel of the reference, frame_buffer.cpp:172-177)
+                        uint32_t frame = A.frame_begin + f;
+                        sampler.start(px, py, frame, 0);
+                        ps.ray = generate_ray(P, px, py, sampler);
+                        sampler.start(px, py, frame, 1); // path_tracing kernel, integrator.cpp:93
+                        path_begin(ps);
+                        has_path = true; item = w;
+                        cnt.paths++;
                     }
                 }
             }
+            w_lo = min(w_lo + (uint32_t) __popcll(need_mask), w_hi);
         }
-        if (!__any(has_pixel || !queue_empty)) break;
-
-        // ---- start a new path: ray generation (rt_geom kernel of the reference, frame_buffer.cpp:172-177) ----
-        if (has_pixel && !path_alive) {
-            sampler.start(px, py, frame, 0);
-            ps.ray = generate_ray(P, px, py, sampler);
-            sampler.start(px, py, frame, 1); // path_tracing kernel, integrator.cpp:93
-            path_begin(ps);
-            path_alive = true;
-            cnt.paths++;
-        }
+        if (!__any(has_path) && exhausted && w_lo >= w_hi) break;
 
         // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
-        // (all lanes take part: the traversals inside are wave-cooperative; lanes without a pixel contribute no ray)
-        bool terminate = path_bounce<FULL>(S, P, ws, ps, sampler, cnt, nullptr, has_pixel);
-        if (has_pixel && terminate) { // RGBFilm accumulation, frame_buffer.cpp:117-126
-            float a = 1.f / (float) (frame + 1u);
-            V4 val = {ps.L.x, ps.L.y, ps.L.z, 1.f};
-            acc = lerp4(a, acc, val);
-            path_alive = false;
-            ++frame;
-            if (frame >= frame_end) {
-                A.accum[(size_t) py * P->width + px] = make_float4(acc.x, acc.y, acc.z, acc.w);
-                has_pixel = false;
-            }
+        // (all lanes take part: the traversals inside are wave-cooperative; lanes without a path contribute no ray)
+        bool terminate = path_bounce<FULL>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
+        if (has_path && terminate) {
+            A.stage[item] = make_float4(ps.L.x, ps.L.y, ps.L.z, 1.f);
+            has_path = false;
         }
     }
     // ---- counters: one atomic per wave and counter ----
@@ -410,6 +411,24 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
         uint32_t s = wave_sum(c[i]);
         if (lane == 0 && s) atomicAdd(A.counters + i, (unsigned long long) s);
     }
+}
+
+// RGBFilm accumulation (frame_buffer.cpp:117-126): acc = lerp(1/(f+1), acc, L_f), frame by frame for every owned pixel
+__global__ void k_film_resolve(RenderArgs A) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= A.n_slots) return;
+    uint32_t px, py;
+    const uint32_t width = A.params->width;
+    if (!slot_to_pixel(A, slot, width, A.params->height, &px, &py)) return;
+    float4 a4 = A.accum[(size_t) py * width + px];
+    V4 acc = {a4.x, a4.y, a4.z, a4.w};
+    for (uint32_t f = 0; f < A.frame_count; ++f) {
+        float4 l = A.stage[(size_t) f * A.n_slots + slot];
+        float a = 1.f / (float) (A.frame_begin + f + 1u);
+        V4 val = {l.x, l.y, l.z, 1.f};
+        acc = lerp4(a, acc, val);
+    }
+    A.accum[(size_t) py * width + px] = make_float4(acc.x, acc.y, acc.z, acc.w);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -596,7 +615,7 @@ struct vmk_ctx {
     // render state
     vmk_render_params params{};
     DevBuf<vmk_render_params> d_params;
-    DevBuf<float4> own_fb, tm_out;
+    DevBuf<float4> own_fb, tm_out, stage;
     float4 *fb{nullptr};
     DevBuf<uint32_t> queue;
     DevBuf<unsigned long long> counters;
@@ -642,7 +661,7 @@ void vmk_destroy(vmk_ctx *ctx) {
     ctx->tri_pos_in.release(); ctx->tri_pos.release(); ctx->tri_attr_in.release(); ctx->tri_attr.release(); ctx->tri_lookup.release();
     ctx->instances.release(); ctx->materials.release(); ctx->lights.release(); ctx->textures.release(); ctx->tex_data.release();
     ctx->alias_prob.release(); ctx->alias_func.release(); ctx->alias_idx.release(); ctx->srgb_lut.release(); ctx->luts.release();
-    ctx->nodes.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release();
+    ctx->nodes.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release(); ctx->stage.release();
     ctx->queue.release(); ctx->counters.release();
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
@@ -901,10 +920,10 @@ int vmk_reset_accum(vmk_ctx *ctx) {
 int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, const vmk_tiles *tiles, float *kernel_ms) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready || !ctx->fb) { ctx->error = "vmk_render_batch: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    if (kernel_ms) *kernel_ms = 0.f;
     if (frame_count == 0) return VMK_OK;
     RenderArgs A{};
     A.scene = ctx->d_scene.p; A.params = ctx->d_params.p; A.accum = ctx->fb; A.queue = ctx->queue.p; A.counters = ctx->counters.p;
-    A.frame_begin = frame_begin; A.frame_count = frame_count;
     uint32_t ts = kDefaultTile, rank = 0, world = 1;
     if (tiles && tiles->tile_size) {
         ts = tiles->tile_size; rank = tiles->rank; world = tiles->world ? tiles->world : 1;
@@ -916,20 +935,36 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     uint32_t n_tiles = A.tiles_x * A.tiles_y;
     uint32_t owned = n_tiles > rank ? (n_tiles - rank + world - 1) / world : 0;
     A.rank = rank; A.world = world;
-    uint64_t n_work = (uint64_t) owned * ts * ts;
-    if (n_work > 0xffffffffull) { ctx->error = "vmk_render_batch: too many work items"; return VMK_ERR_ARG; }
-    A.n_work = (uint32_t) n_work;
-    if (A.n_work == 0) { if (kernel_ms) *kernel_ms = 0.f; return VMK_OK; }
+    uint64_t n_slots = (uint64_t) owned * ts * ts;
+    if (n_slots == 0) return VMK_OK;
+    if (n_slots > 0x7fffffffull) { ctx->error = "vmk_render_batch: too many pixels"; return VMK_ERR_ARG; }
+    A.n_slots = (uint32_t) n_slots;
     HIP_TRY(hipSetDevice(ctx->device));
+    // frames per launch: bounded by the staging planes (<= 8 GiB) and the 32-bit item index
+    uint64_t max_frames = std::min<uint64_t>((8ull << 30) / (n_slots * sizeof(float4)), 0xffffffffull / n_slots);
+    if (max_frames == 0) max_frames = 1;
+    const uint32_t per_launch = (uint32_t) std::min<uint64_t>(frame_count, max_frames);
+    if (ctx->stage.n < (size_t) per_launch * n_slots) HIP_TRY(ctx->stage.alloc((size_t) per_launch * n_slots));
+    A.stage = ctx->stage.p;
     int per_cu = 0;
     auto kernel = ctx->full_materials ? k_render<true> : k_render<false>;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
-    uint32_t grid = (uint32_t) std::min<uint64_t>((n_work + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * (uint64_t) per_cu);
-    HIP_TRY(hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream));
     if (kernel_ms) HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
-    HIP_TRY(hipGetLastError());
+    for (uint32_t done = 0; done < frame_count; done += per_launch) {
+        A.frame_begin = frame_begin + done; A.frame_count = std::min(per_launch, frame_count - done);
+        const uint64_t n_items = (uint64_t) A.frame_count * n_slots;
+        A.n_items = (uint32_t) n_items;
+        uint32_t grid = (uint32_t) std::min<uint64_t>((n_items + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * (uint64_t) per_cu);
+        // a wave claims `chunk` items per atomic: few enough claims to keep the counter cold, small enough to balance the tail
+        uint64_t chunk = (n_items / ((uint64_t) grid * (kBlock / 64) * 8)) & ~63ull;
+        A.chunk = (uint32_t) std::max<uint64_t>(64, std::min<uint64_t>(1024, chunk));
+        HIP_TRY(hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_film_resolve, dim3((A.n_slots + 255) / 256), dim3(256), 0, ctx->stream, A);
+        HIP_TRY(hipGetLastError());
+    }
     if (kernel_ms) {
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(hipEventSynchronize(ctx->ev1));
