@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VMK_ABI_VERSION 1u
+#define VMK_ABI_VERSION 2u
 #define VMK_INVALID 0xFFFFFFFFu
 
 typedef enum vmk_status {
@@ -139,7 +139,14 @@ typedef struct vmk_instance { /* InstanceData, src/base/shape.h:21-33 */
     uint32_t tri_offset, tri_count;
     float n2w[9];      /* normal matrix: transpose(inverse(o2w 3x3)), column-major (Transform::apply_normal) */
     float o2w[16];     /* kept for reference / debugging */
+    uint32_t inside_medium, outside_medium; /* indices into mediums[] or VMK_INVALID (shape.cpp:246-271, scene.cpp:135-147) */
 } vmk_instance;
+
+/* ---- participating media (render_core/medium/homogeneous.cpp:11-70) ------------------------------------ */
+typedef struct vmk_medium { /* "homogeneous": sigma_t = (sigma_a + sigma_s) * scale, Henyey-Greenstein g clamped to +-0.99 */
+    float sigma_a[3], sigma_s[3];
+    float g, scale;
+} vmk_medium;
 
 /* ---- textures ----------------------------------------------------------------------------------- */
 typedef enum vmk_tex_format { VMK_TEX_RGBA8_SRGB = 0, VMK_TEX_RGBA8_LINEAR = 1, VMK_TEX_RGBA32F = 2 } vmk_tex_format;
@@ -180,6 +187,8 @@ typedef struct vmk_scene {
     uint32_t env_light;          /* index of the environment light in lights[] or VMK_INVALID */
     float world_min[3], world_max[3];
     vmk_luts luts;
+    uint32_t n_mediums;
+    const vmk_medium *mediums; /* MediumRegistry order (scene.cpp:189-199) */
 } vmk_scene;
 
 /* ---- camera / film / integrator ---------------------------------------------------------------------- */
@@ -214,6 +223,10 @@ typedef struct vmk_render_params {
     /* FrameBuffer (frame_buffer.cpp:15-26) */
     float exposure;
     uint32_t tone_mapper; /* 0 linear, 1 aces, 2 reinhard (tonemapper/impl.cpp:16-45) */
+    /* participating media: Scene::process_mediums() (scene_desc.cpp:26-35) and the sensor's medium
+     * (photosensory.cpp:11-32, sensor.cpp:48) */
+    uint32_t process_mediums;
+    uint32_t camera_medium; /* index into mediums[] or VMK_INVALID */
 } vmk_render_params;
 
 /* Tile ownership for multi-GPU sharding: image cut into tile_size^2 tiles in row-major order, tile t is
@@ -281,6 +294,14 @@ int vmk_accel_info_get(vmk_ctx *ctx, vmk_accel_info *out);
  * hit[i*4] = 1/0.  Returns kernel time of the traversal launch in *kernel_ms. */
 int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *dir_xyz, const float *tmax,
                    int any_hit, uint32_t *hit_out /* n*4 */, float *kernel_ms, uint32_t repeats);
+
+/* ---- albedo-table precompute (the reference's vision-precompute app, src/apps/precompute/main.cpp:24-41;
+ * Material::precompute_lobe base/scattering/material.h:121-163; Lobe::integral_albedo lobe.cpp:13-33) --------
+ * Integrates table `which` (0 PureReflection res^2, 1 Dielectric / 2 DielectricInv res^3 x 2 floats {total,
+ * reflected}, 3 Specular res^3, 4 Coat res^3) with sample_num samples per texel on the GPU; out is a host
+ * array in the layout vmk_luts expects.  Needs no scene.  tools/make_luts.py builds vision_amd/data/luts.bin
+ * with it. */
+int vmk_precompute_albedo(vmk_ctx *ctx, uint32_t which, uint32_t res, uint32_t sample_num, float *out);
 
 /* ---- device-side unit entry points used by the parity tests (tests/ only) ------------------------------ */
 /* Evaluate n independent work items of test `kind` on the GPU; in/out are plain float arrays with

@@ -30,6 +30,8 @@ typedef struct vmk_host_options {
     uint32_t procedural_env;    /* 1: a missing environment image is replaced by the seeded procedural sky */
     uint32_t drop_unsupported_lights; /* 1: skip light types outside the hot-path scope (point/spot/projector) instead of failing */
     const char *lut_path;       /* albedo-table blob (vision_amd/data/luts.bin); NULL = default next to the library */
+    uint32_t mediums;           /* 0: ignore the scene's "mediums" block (the non-fog variant, BASELINE config 3);
+                                 * 1: honour it (mediums.process, global medium, per-shape inside/outside, sensor medium) */
 } vmk_host_options;
 
 /* Register decoded pixels for an image file so the loader does not need a decoder for it.  `path` is matched

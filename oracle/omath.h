@@ -114,6 +114,23 @@ inline float exp_(float x) {
                 1.6666665459e-1f) * x + 5.0000001201e-1f) * x2 + x + 1.f;
     return p * u2f((uint32_t) (n + 127) << 23);
 }
+inline float log_(float x) { // Cephes logf for normal x > 0 (callers pass 1 - u with u in [0,1))
+    if (!(x > 0.f)) return x == 0.f ? -__builtin_inff() : __builtin_nanf("");
+    uint32_t ix = f2u(x);
+    int e = (int) (ix >> 23) - 126; // x = m * 2^e, m in [0.5, 1)
+    float m = u2f((ix & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.f; } else m = m - 1.f;
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m +
+                   1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m +
+               3.3333331174e-1f) * m * z;
+    float fe = (float) e;
+    y += -2.12194440e-4f * fe;
+    y += -0.5f * z;
+    float r = m + y;
+    r += 0.693359375f * fe;
+    return r;
+}
 
 // ---- vectors ----
 struct float2 { float x, y; };

@@ -333,8 +333,11 @@ struct Interaction {
     Frame shading;
     float prim_area{0.f};
     uint32_t prim_id{VMK_INVALID}, mat_id{VMK_INVALID}, light_id{VMK_INVALID};
+    uint32_t med_inside{VMK_INVALID}, med_outside{VMK_INVALID}; // MediumInterface, interaction.h:121-133
+    bool phase{false}; float g{0.f};                            // HenyeyGreenstein valid() / g_, interaction.h:160-175
     bool has_material() const { return mat_id != VMK_INVALID; }
     bool has_emission() const { return light_id != VMK_INVALID; }
+    bool has_phase() const { return phase; }
 };
 inline float3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
 inline float2 ld2(const float *p) { return {p[0], p[1]}; }
@@ -352,6 +355,7 @@ inline Interaction compute_surface_interaction(const vmk_scene *s, uint32_t tri,
     const vmk_tri_pos &tp = s->tri_pos[tri];
     const vmk_tri_attr &ta = s->tri_attr[tri];
     it.prim_id = prim_id; it.light_id = inst.light_id; it.mat_id = inst.mat_id;
+    it.med_inside = inst.inside_medium; it.med_outside = inst.outside_medium; // geometry.cpp:90
     float3 p0 = ld3(tp.p0), p1 = ld3(tp.p1), p2 = ld3(tp.p2);
     it.pos = triangle_lerp(bary, p0, p1, p2);
     float3 dp02 = p0 - p2, dp12 = p1 - p2;
@@ -1203,7 +1207,67 @@ inline Ray generate_ray(const vmk_render_params &p, uint32_t px, uint32_t py, Sa
 }
 
 // =====================================================================================================
-// a20. IlluminationIntegrator::Li — base/integral/integrator.cpp:160-311 (no media), direct_lighting :20-37,
+// §8f-1. Homogeneous medium + Henyey-Greenstein phase function — render_core/medium/homogeneous.cpp:30-70,
+//        base/scattering/interaction.h:136-139, interaction.cpp:12-32,114-134, geometry.cpp:187-199
+// =====================================================================================================
+inline float3 medium_sigma_t(const vmk_medium &m) { return (ld3(m.sigma_a) + ld3(m.sigma_s)) * m.scale; } // homogeneous.cpp:30
+inline float3 medium_sigma_s(const vmk_medium &m) { return ld3(m.sigma_s) * m.scale; }                    // :31
+inline float3 exp3(float3 v) { return make_float3(exp_(v.x), exp_(v.y), exp_(v.z)); }
+inline float3 medium_Tr(const vmk_medium &m, float t) { return exp3((-1.f * medium_sigma_t(m)) * fmin_(RayTMax, t)); } // :33-36
+inline float3 medium_Tr_ray(const vmk_medium &m, const Ray &r) { return medium_Tr(m, length(r.d) * r.t_max); }        // :45-48
+// Geometry::Tr geometry.cpp:187-199
+inline float3 geometry_Tr(const vmk_scene *s, const vmk_render_params &p, const Ray &r, uint32_t medium) {
+    if (p.process_mediums && medium != VMK_INVALID) return medium_Tr_ray(s->mediums[medium], r);
+    return make_float3(1.f);
+}
+// the medium a ray spawned at `it` towards dir travels in — Interaction::spawn_ray_state interaction.cpp:114-123
+inline uint32_t spawn_medium(const vmk_render_params &p, const Interaction &it, float3 dir) {
+    if (!p.process_mediums) return VMK_INVALID;
+    return dot(it.ng, dir) > 0.f ? it.med_outside : it.med_inside;
+}
+inline float phase_HG(float cos_theta, float g) { // interaction.h:136-139
+    float denom = 1.f + sqr(g) + 2.f * g * cos_theta;
+    return Inv4Pi * (1.f - sqr(g)) / (denom * sqrtf(denom));
+}
+// HomogeneousMedium::sample homogeneous.cpp:50-70 (2 draws); may replace `it` by a medium interaction
+inline float3 medium_sample(const vmk_medium &m, uint32_t medium_id, const Ray &ray, Interaction &it, Sampler &sampler) {
+    float3 sigma_t = medium_sigma_t(m), sigma_s = medium_sigma_s(m);
+    uint32_t channel = (uint32_t) (sampler.next_1d() * 3.f); if (channel > 2u) channel = 2u;
+    float st_c = channel == 0 ? sigma_t.x : (channel == 1 ? sigma_t.y : sigma_t.z);
+    float dist = -log_(1.f - sampler.next_1d()) / st_c;
+    float t = fmin_(dist / length(ray.d), ray.t_max);
+    bool sampled_medium = t < ray.t_max;
+    if (sampled_medium) { // Interaction(ray->at(t), -ray->direction(), true); init_phase; set_medium
+        Interaction mi;
+        mi.pos = ray.o + ray.d * t; mi.wo = -1.f * ray.d; mi.ng = make_float3(0.f);
+        mi.uv = make_float2(0.f, 0.f);
+        mi.phase = true; mi.g = m.g;
+        mi.med_inside = medium_id; mi.med_outside = medium_id;
+        it = mi;
+    }
+    float3 tr = medium_Tr(m, t);
+    float3 density = sampled_medium ? sigma_t * tr : tr;
+    float pdf = (density.x + density.y + density.z) / 3.f;
+    return sampled_medium ? tr * sigma_s / pdf : tr / pdf;
+}
+// HenyeyGreenstein::sample interaction.cpp:16-32 (2 draws)
+inline float3 hg_sample(float3 wo, float g, Sampler &sampler, float *f_out) {
+    float2 u = sampler.next_2d();
+    float sqr_term = (1.f - sqr(g)) / (1.f + g - 2.f * g * u.x);
+    float cos_theta = -(1.f + sqr(g) - sqr(sqr_term)) / (2.f * g);
+    cos_theta = abs_(g) < 1e-3f ? 1.f - 2.f * u.x : cos_theta;
+    float sin_theta = safe_sqrt(1.f - sqr(cos_theta));
+    float phi = 2.f * Pi * u.y;
+    float3 v1, v2;
+    coordinate_system(wo, &v1, &v2);
+    float sp, cp; sincos_(phi, &sp, &cp);
+    float3 wi = sin_theta * cp * v1 + sin_theta * sp * v2 + cos_theta * wo; // spherical_direction(sin, cos, phi, x, y, z)
+    *f_out = phase_HG(cos_theta, g);
+    return wi;
+}
+
+// =====================================================================================================
+// a20. IlluminationIntegrator::Li — base/integral/integrator.cpp:160-311, direct_lighting :20-37,
 //      evaluate_miss :137-158
 // =====================================================================================================
 struct PathStats { uint32_t closest{0}, shadow{0}, hits{0}; };
@@ -1216,6 +1280,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
     float scatter_pdf = 1e16f;
     float eta_scale = 1.f;
     float3 prev_surface_ng = ray.d;
+    uint32_t ray_medium = p.process_mediums ? p.camera_medium : VMK_INVALID; // RayState::medium, sensor.cpp:48
     auto correct_bsdf_weight = [&](float weight, uint32_t bounce) { // integrator.h:146-159
         if (p.mis_mode == 2) return 1.f;
         if (p.mis_mode == 1) return bounce == 0 ? weight : 0.f;
@@ -1236,17 +1301,21 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
             break;
         }
         Interaction it = compute_surface_interaction(s, hit, ray);
-        if (!it.has_material()) { // integrator.cpp:208-214
+        if (p.process_mediums && ray_medium != VMK_INVALID) // integrator.cpp:199-206
+            T *= medium_sample(s->mediums[ray_medium], ray_medium, ray, it, sampler);
+        if (!it.has_material() && !it.has_phase()) { // integrator.cpp:208-214
+            ray_medium = spawn_medium(p, it, ray.d);
             ray = spawn_ray(it.pos, it.ng, ray.d);
             bounces -= 1;
             continue;
         }
-        tl_cnt.hits++;
+        if (!it.has_phase()) tl_cnt.hits++;
         if (it.has_emission()) { // integrator.cpp:221-231
             LightSampleContext p_ref{ray.o, prev_surface_ng};
             LightEval eval = light_evaluate_hit_wi(lc, p_ref, it);
+            float3 tr = geometry_Tr(s, p, ray, ray_medium);
             float weight = correct_bsdf_weight(MIS_weight(scatter_pdf, eval.pdf), bounces);
-            L += eval.L * T * weight * 1.f;
+            L += eval.L * T * weight * tr;
         }
         prev_surface_ng = it.ng;
         // NEE
@@ -1254,12 +1323,23 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         LightSample ls = light_sample_wi(lc, lsc, sampler);
         Ray shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
         bool occluded = sv.trace_occlusion(shadow_ray);
-        LobeSet lobes;
-        build_lobe_set(s, s->materials[it.mat_id], it, lobes);
+        float3 tr = geometry_Tr(s, p, shadow_ray, spawn_medium(p, it, shadow_ray.d)); // geometry.cpp:176-185, integrator.cpp:244
         // direct_lighting (integrator.cpp:20-37) via direct_light_mis (integrator.h:164-176)
         float3 wi = normalize(ls.p_light - it.pos);
-        ScatterEval scatter_eval = evaluator_evaluate(s, lobes, it.ng, it.wo, wi);
-        BSDFSample bs = evaluator_sample(s, lobes, it.ng, it.wo, sampler);
+        ScatterEval scatter_eval;
+        BSDFSample bs;
+        if (it.has_phase()) { // integrator.cpp:271-279: the phase function stands in for the BSDF
+            float f = phase_HG(dot(it.wo, wi), it.g);
+            scatter_eval.f = make_float3(f); scatter_eval.pdf = f; scatter_eval.flags = 0;
+            float fs;
+            bs.wi = hg_sample(it.wo, it.g, sampler, &fs);
+            bs.eval.f = make_float3(fs); bs.eval.pdf = fs; bs.eval.flags = 0;
+        } else {
+            LobeSet lobes;
+            build_lobe_set(s, s->materials[it.mat_id], it, lobes);
+            scatter_eval = evaluator_evaluate(s, lobes, it.ng, it.wo, wi);
+            bs = evaluator_sample(s, lobes, it.ng, it.wo, sampler);
+        }
         if (rec) { rec[4] = ls.eval.pdf; rec[5] = scatter_eval.pdf; rec[6] = bs.eval.pdf; rec[7] = occluded ? 1.f : 0.f; }
         bool is_delta_light = ls.eval.pdf < 0.f;
         bool mis = p.mis_mode != 1;
@@ -1268,7 +1348,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         float3 Ld = make_float3(0.f);
         if (!occluded && scatter_eval.valid() && ls.valid()) Ld = ls.eval.L * scatter_eval.f * weight / ls.eval.pdf;
         if (p.mis_mode == 2) Ld = Ld * 0.f;
-        L += T * Ld * 1.f;
+        L += T * Ld * tr;
         eta_scale *= sqr(bs.eta);
         float lum = max_comp(T);
         if (!bs.valid() || lum == 0.f) break;
@@ -1280,6 +1360,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
             T = T / q;
         }
         scatter_pdf = bs.eval.pdf;
+        ray_medium = spawn_medium(p, it, bs.wi);
         ray = spawn_ray(it.pos, it.ng, bs.wi);
     }
     return L;
@@ -1438,6 +1519,7 @@ int orc_test_eval(void *h, const vmk_render_params *p, uint32_t kind, uint32_t n
             case 1: {
                 float s, c; sincos_(a[0], &s, &c);
                 o[0] = s; o[1] = c; o[2] = acos_(clamp_(a[0], -1.f, 1.f)); o[3] = atan2_(a[1], a[0]); o[4] = exp_(-abs_(a[0])); o[5] = sqrtf(abs_(a[0]));
+                if (out_stride >= 7) o[6] = log_(abs_(a[0]) * 0.125f + 5.9604645e-8f);
                 break;
             }
             case 2: {

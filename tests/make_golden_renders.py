@@ -2,7 +2,7 @@
 """Golden radiance fixtures: linear accumulation buffers rendered by the CPU oracle (tests/golden/*.npy).
 
 SURVEY.md §8c fixture (iii): no linear-radiance golden exists in the reference tree, so the GPU parity fixtures are
-the CPU restatement's output on fixed (scene, resolution, frame range).   python tools/make_golden_renders.py
+the CPU restatement's output on fixed (scene, resolution, frame range).   python tests/make_golden_renders.py
 """
 import os, sys
 import numpy as np
@@ -12,9 +12,11 @@ from vision_amd.host import HostScene
 from oracle import oracle_py
 
 CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materials", "scenes/cbox/cbox_materials.json", 32, 32, 4),
-         ("classroom", "scenes/classroom/vision_scene.json", 48, 27, 2)]
+         ("classroom", "scenes/classroom/vision_scene.json", 48, 27, 2),
+         ("cbox_media", "scenes/cbox/cbox_media.json", 32, 32, 4), ("classroom_fog", "scenes/classroom/vision_scene.json", 48, 27, 2)]
+MEDIA = {"cbox_media", "classroom_fog"}  # rendered with the scene's "mediums" block honoured
 for name, path, w, h, spp in CASES:
-    hs = HostScene(os.path.join(ROOT, path), width=w, height=h)
+    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA)
     img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
     out = os.path.join(ROOT, "tests", "golden", f"{name}_{w}x{h}x{spp}.npy")
     np.save(out, img)

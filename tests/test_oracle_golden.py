@@ -40,13 +40,14 @@ def test_tea_lcg_known_answers(built):
 
 
 def test_elementary_functions_accuracy(built):
-    """The deterministic sin/cos/acos/atan2/exp kernels stay within 2.5 ulp (atan2: 4 ulp) of double-precision libm on their domains."""
+    """The deterministic sin/cos/acos/atan2/exp/log kernels stay within 2.5 ulp (atan2: 4 ulp) of double-precision libm on their domains."""
     rng = np.random.default_rng(1)
     x = np.concatenate([rng.uniform(-7, 7, 20000), np.linspace(-1, 1, 2001)]).astype(np.float32)
     y = rng.uniform(-3, 3, x.shape[0]).astype(np.float32)
-    out = oracle_py.test_eval_noscene(1, np.stack([x, y], 1), 6)
+    out = oracle_py.test_eval_noscene(1, np.stack([x, y], 1), 7)
     xd, yd = x.astype(np.float64), y.astype(np.float64)
-    ref = [np.sin(xd), np.cos(xd), np.arccos(np.clip(xd, -1, 1)), np.arctan2(yd, xd), np.exp(-np.abs(xd)), np.sqrt(np.abs(xd))]
+    lx = (np.abs(x) * np.float32(0.125) + np.float32(5.9604645e-8)).astype(np.float64)  # the unit's log argument, (0, 1)
+    ref = [np.sin(xd), np.cos(xd), np.arccos(np.clip(xd, -1, 1)), np.arctan2(yd, xd), np.exp(-np.abs(xd)), np.sqrt(np.abs(xd)), np.log(lx)]
     for k, r in enumerate(ref):
         ulp = np.spacing(np.maximum(np.abs(r), 1e-3).astype(np.float32)).astype(np.float64)
         assert np.max(np.abs(out[:, k].astype(np.float64) - r) / ulp) <= (4.0 if k == 3 else 2.5), k

@@ -13,17 +13,26 @@ from vision_amd.host import HostScene
 from oracle import oracle_py
 
 CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materials", "scenes/cbox/cbox_materials.json", 32, 32, 4),
-         ("classroom", "scenes/classroom/vision_scene.json", 48, 27, 2)]
+         ("classroom", "scenes/classroom/vision_scene.json", 48, 27, 2),
+         # participating media honoured (vmk_host_options.mediums = 1): global fog + a material-less smoke volume; classroom's own fog
+         ("cbox_media", "scenes/cbox/cbox_media.json", 32, 32, 4), ("classroom_fog", "scenes/classroom/vision_scene.json", 48, 27, 2)]
+MEDIA = {"cbox_media", "classroom_fog"}
 
 
 @pytest.mark.parametrize("name, path, w, h, spp", CASES)
 def test_oracle_matches_committed_golden(built, name, path, w, h, spp):
-    hs = HostScene(os.path.join(ROOT, path), width=w, height=h)
+    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA)
+    assert bool(hs.params.process_mediums) == (name in MEDIA)
     img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
     gold = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_{w}x{h}x{spp}.npy"))
     assert np.array_equal(img.view(np.uint32), gold.view(np.uint32))  # deterministic: bit-exact across threads/runs
     assert np.isfinite(img).all() and cnt["paths"] == w * h * spp
-    assert cnt["shadow_rays"] == cnt["surface_hits"]  # one shadow ray per shaded vertex (integrator.cpp:241-243)
+    if name in MEDIA:  # scattering events inside the medium also cast a shadow ray (integrator.cpp:241-243,271-279)
+        assert cnt["shadow_rays"] > cnt["surface_hits"]
+        plain = HostScene(os.path.join(ROOT, path), width=w, height=h)
+        assert not plain.params.process_mediums and plain.scene.n_mediums == 0  # default: the non-fog variant
+    else:
+        assert cnt["shadow_rays"] == cnt["surface_hits"]  # one shadow ray per shaded vertex
 
 
 def test_batch_split_and_tile_sharding_are_exact(built):

@@ -1,7 +1,7 @@
 """ctypes mirror of include/vmk.h and include/vmk_host.h (plain C structs, no torch types)."""
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 INVALID = 0xFFFFFFFF
 MAX_SLOTS = 18
 LUT_RES = 32
@@ -35,7 +35,11 @@ class TriAttr(C.Structure):
 
 class Instance(C.Structure):
     _fields_ = [("mat_id", u32), ("light_id", u32), ("tri_offset", u32), ("tri_count", u32), ("n2w", f32 * 9),
-                ("o2w", f32 * 16)]
+                ("o2w", f32 * 16), ("inside_medium", u32), ("outside_medium", u32)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("sigma_a", f32 * 3), ("sigma_s", f32 * 3), ("g", f32), ("scale", f32)]
 
 
 class Texture(C.Structure):
@@ -54,7 +58,8 @@ class Scene(C.Structure):
                 ("materials", C.POINTER(Material)), ("lights", C.POINTER(Light)), ("textures", C.POINTER(Texture)),
                 ("tex_data", C.POINTER(C.c_uint8)), ("tex_bytes", u64),
                 ("alias_prob", C.POINTER(f32)), ("alias_idx", C.POINTER(u32)), ("alias_func", C.POINTER(f32)),
-                ("env_light", u32), ("world_min", f32 * 3), ("world_max", f32 * 3), ("luts", Luts)]
+                ("env_light", u32), ("world_min", f32 * 3), ("world_max", f32 * 3), ("luts", Luts),
+                ("n_mediums", u32), ("mediums", C.POINTER(Medium))]
 
 
 _T = FILTER_TABLE_SIZE
@@ -69,7 +74,7 @@ class RenderParams(C.Structure):
                 ("filter_cond_func", f32 * (_T * _T)),
                 ("max_depth", u32), ("min_depth", u32), ("rr_threshold", f32), ("mis_mode", u32),
                 ("env_separate", u32), ("env_prob", f32), ("ray_offset_factor", f32), ("exposure", f32),
-                ("tone_mapper", u32)]
+                ("tone_mapper", u32), ("process_mediums", u32), ("camera_medium", u32)]
 
 
 class Tiles(C.Structure):
@@ -91,14 +96,15 @@ class AccelInfo(C.Structure):
 
 class HostOptions(C.Structure):
     _fields_ = [("width", u32), ("height", u32), ("max_depth", i32), ("min_depth", i32), ("procedural_env", u32),
-                ("drop_unsupported_lights", u32), ("lut_path", C.c_char_p)]
+                ("drop_unsupported_lights", u32), ("lut_path", C.c_char_p), ("mediums", u32)]
 
 
 # every symbol include/vmk.h declares (checked by tests/test_abi.py without a GPU)
 VMK_SYMBOLS = ["vmk_create", "vmk_destroy", "vmk_last_error", "vmk_abi_version", "vmk_upload_scene",
                "vmk_build_accel", "vmk_set_render_params", "vmk_set_framebuffer", "vmk_reset_accum",
                "vmk_render_batch", "vmk_synchronize", "vmk_download_accum", "vmk_tonemap", "vmk_get_counters",
-               "vmk_reset_counters", "vmk_stream", "vmk_accel_info_get", "vmk_trace_rays", "vmk_test_eval"]
+               "vmk_reset_counters", "vmk_stream", "vmk_accel_info_get", "vmk_trace_rays", "vmk_test_eval",
+               "vmk_precompute_albedo"]
 HOST_SYMBOLS = ["vmk_host_register_image", "vmk_host_clear_images", "vmk_host_list_images", "vmk_host_load_scene",
                 "vmk_host_free_scene", "vmk_host_scene_tables", "vmk_host_render_params", "vmk_host_output_spp",
                 "vmk_host_output_fn", "vmk_host_describe", "vmk_host_last_error"]

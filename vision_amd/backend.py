@@ -51,6 +51,7 @@ def lib():
         L.vmk_accel_info_get.argtypes = [C.c_void_p, C.c_void_p]
         L.vmk_trace_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.POINTER(C.c_float), C.c_uint32]
+        L.vmk_precompute_albedo.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.vmk_test_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         if L.vmk_abi_version() != _abi.ABI_VERSION:
             raise BackendError("libvmk.so ABI version mismatch")
@@ -145,6 +146,13 @@ class Backend:
         self._check(self._L.vmk_test_eval(self._h, kind, inp.shape[0], _ptr(inp), inp.shape[1], _ptr(out), out_stride))
         return out
 
+    def precompute_albedo(self, which, res=32, samples=1 << 17):
+        """Albedo table `which` (include/vmk.h: vmk_precompute_albedo) as a flat float32 array."""
+        n = res * res * (1 if which == 0 else res) * (2 if which in (1, 2) else 1)
+        out = np.zeros(n, np.float32)
+        self._check(self._L.vmk_precompute_albedo(self._h, which, res, samples, _ptr(out)))
+        return out
+
     def capture_rays(self, pixels_xy, frame=0):
         """Rays the megakernel traces for `frame` of the given pixels (k_test kind 7), as SoA arrays ordered by
         (vertex, ray kind, pixel) — i.e. what the lanes of one wave trace together.  Feeds trace() replays."""
@@ -169,3 +177,12 @@ class Backend:
             self.close()
         except Exception:
             pass
+
+
+def precompute_albedo_tables(samples=1 << 17, res=32, device=0):
+    """The five albedo-compensation tables in vmk_luts order, integrated on the GPU (tools/make_luts.py)."""
+    be = Backend(device)
+    try:
+        return [be.precompute_albedo(w, res, samples) for w in range(5)]
+    finally:
+        be.close()

@@ -160,8 +160,6 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
     uint32_t binst = VMK_INVALID, bprim = VMK_INVALID, btri = VMK_INVALID;
     bool found = false;
     uint32_t nn = 0, nt = 0, nr = 0;
-    // lane-constant tie-break bits for the child ordering: does quad lane (q ^ k) come before me?
-    const bool before1 = (q ^ 1u) < q, before2 = (q ^ 2u) < q, before3 = (q ^ 3u) < q;
 #define VMK_POP() do { if (sp > 0) { --sp; cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
 
     for (;;) {
@@ -183,9 +181,12 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 // everywhere, from walking into them)
                 bool h = hit_box(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, o, inv, best_t, &tn) && ref != kEmptyRef;
                 nn += q == 0 ? 1u : 0u;
-                float t = h ? tn : __builtin_inff(); // misses are never ranked before a hit
-                float t1 = quad_perm_f<kQuadXor1>(t), t2 = quad_perm_f<kQuadXor2>(t), t3 = quad_perm_f<kQuadXor3>(t);
-                int rank = ((t1 < t || (t1 == t && before1)) ? 1 : 0) + ((t2 < t || (t2 == t && before2)) ? 1 : 0) + ((t3 < t || (t3 == t && before3)) ? 1 : 0);
+                // order key: entry distance (non-negative float bits order like integers) with the lane id in the two low
+                // mantissa bits, so keys are distinct and three unsigned compares rank the children; misses sort last.  The
+                // visiting order only steers culling, it never changes which hit is returned.
+                uint32_t key = h ? ((f2u(tn) & ~3u) | q) : 0xffffffffu;
+                uint32_t k1 = (uint32_t) quad_perm_i<kQuadXor1>((int32_t) key), k2 = (uint32_t) quad_perm_i<kQuadXor2>((int32_t) key), k3 = (uint32_t) quad_perm_i<kQuadXor3>((int32_t) key);
+                int rank = (k1 < key ? 1 : 0) + (k2 < key ? 1 : 0) + (k3 < key ? 1 : 0);
                 int n = h ? 1 : 0;
                 n += quad_perm_i<kQuadXor1>(n);
                 n += quad_perm_i<kQuadXor2>(n);

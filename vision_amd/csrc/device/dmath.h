@@ -110,6 +110,24 @@ VD float exp_(float x) {
                 1.6666665459e-1f) * x + 5.0000001201e-1f) * x2 + x + 1.f;
     return p * u2f((uint32_t) (n + 127) << 23);
 }
+VD float log_(float x) { // Cephes logf for normal x > 0 (callers pass 1 - u with u in [0,1))
+    if (!(x > 0.f)) return x == 0.f ? -__builtin_inff() : __builtin_nanf("");
+    uint32_t ix = f2u(x);
+    int e = (int) (ix >> 23) - 126; // x = m * 2^e, m in [0.5, 1)
+    float m = u2f((ix & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.f; } else m = m - 1.f;
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m +
+                   1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m +
+               3.3333331174e-1f) * m * z;
+    float fe = (float) e;
+    y += -2.12194440e-4f * fe;
+    y += -0.5f * z;
+    float r = m + y;
+    r += 0.693359375f * fe;
+    return r;
+}
+constexpr float Inv4Pi = 0.07957747154594766788f;
 
 // ---- vectors ----
 struct V2 { float x, y; };
@@ -156,6 +174,11 @@ VD bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.f; }
 VD bool same_hemisphere(V3 a, V3 b, V3 n) { return dot(a, n) * dot(b, n) > 0.f; }
 VD V3 face_forward(V3 v, V3 n) { return dot(v, n) < 0.f ? -v : v; }
 VD V3 reflect(V3 wo, V3 n) { return -wo + n * (2.f * dot(wo, n)); }
+VD void coordinate_system(V3 v1, V3 *v2, V3 *v3) {
+    if (abs_(v1.x) > abs_(v1.y)) { float inv = 1.f / sqrt_(v1.x * v1.x + v1.z * v1.z); *v2 = {-v1.z * inv, 0.f, v1.x * inv}; }
+    else { float inv = 1.f / sqrt_(v1.y * v1.y + v1.z * v1.z); *v2 = {0.f, v1.z * inv, -v1.y * inv}; }
+    *v3 = cross(v1, *v2);
+}
 VD V3 spherical_direction(float sin_t, float cos_t, float phi) {
     float s, c; sincos_(phi, &s, &c);
     return {sin_t * c, sin_t * s, cos_t};

@@ -30,6 +30,7 @@ struct DScene {
     const vmk_instance *instances;
     const vmk_material *materials;
     const vmk_light *lights;
+    const vmk_medium *mediums;
     const vmk_texture *textures;
     const uint8_t *tex_data;
     const float *alias_prob;

@@ -217,15 +217,46 @@ struct PathState {
     V3 L, T, prev_ng;
     float scatter_pdf, eta_scale;
     uint32_t bounces;
+    uint32_t medium; // RayState::medium: the medium the current ray travels in (MEDIA variants only)
 };
-__device__ __forceinline__ void path_begin(PathState &ps) {
+__device__ __forceinline__ void path_begin(PathState &ps, const vmk_render_params *P) {
     ps.L = mk3(0.f); ps.T = mk3(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
+    ps.medium = P->process_mediums ? P->camera_medium : VMK_INVALID; // sensor.cpp:48
+}
+
+// ---- homogeneous medium + Henyey-Greenstein (render_core/medium/homogeneous.cpp:30-70, interaction.h:136-139,
+//      interaction.cpp:12-32,114-134, geometry.cpp:187-199) — §8f rank 1 ----
+VD V3 medium_sigma_t(const vmk_medium *m) { return (ld3(m->sigma_a) + ld3(m->sigma_s)) * m->scale; }
+VD V3 medium_sigma_s(const vmk_medium *m) { return ld3(m->sigma_s) * m->scale; }
+VD V3 exp3(V3 v) { return {exp_(v.x), exp_(v.y), exp_(v.z)}; }
+VD V3 medium_Tr(const vmk_medium *m, float t) { return exp3((-1.f * medium_sigma_t(m)) * fmin_(RayTMax, t)); }
+VD V3 geometry_Tr(const DScene &S, const vmk_render_params *P, const Ray &r, uint32_t medium) {
+    if (P->process_mediums && medium != VMK_INVALID) return medium_Tr(S.mediums + medium, length(r.d) * r.t_max);
+    return mk3(1.f);
+}
+VD float phase_HG(float cos_theta, float g) {
+    float denom = 1.f + sqr(g) + 2.f * g * cos_theta;
+    return Inv4Pi * (1.f - sqr(g)) / (denom * sqrt_(denom));
+}
+VD V3 hg_sample(V3 wo, float g, Sampler &sampler, float *f_out) { // 2 draws
+    V2 u = sampler.next_2d();
+    float sqr_term = (1.f - sqr(g)) / (1.f + g - 2.f * g * u.x);
+    float cos_theta = -(1.f + sqr(g) - sqr(sqr_term)) / (2.f * g);
+    cos_theta = abs_(g) < 1e-3f ? 1.f - 2.f * u.x : cos_theta;
+    float sin_theta = safe_sqrt(1.f - sqr(cos_theta));
+    float phi = 2.f * Pi * u.y;
+    V3 v1, v2;
+    coordinate_system(wo, &v1, &v2);
+    float sp, cp; sincos_(phi, &sp, &cp);
+    V3 wi = sin_theta * cp * v1 + sin_theta * sp * v2 + cos_theta * wo;
+    *f_out = phase_HG(cos_theta, g);
+    return wi;
 }
 // One path vertex for every lane of the wave: ALL lanes call this convergently (the two traversals inside are
 // wave-cooperative), `active` says whether the lane carries a live path.  Returns true when the lane's path ends at this
 // vertex.  `dbg` (tests / ray capture only): 16 floats per vertex —
 // [hit inst, prim, bary.xy | light pdf, bsdf pdf towards the light, sampled pdf, occluded | shadow ray o.xyz d.xyz t_max, traced].
-template<bool FULL>
+template<bool FULL, bool MEDIA>
 __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, WaveScratch *ws, PathState &ps, Sampler &sampler,
                                             DCounters &cnt, float *dbg, bool active) {
     const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
@@ -247,19 +278,47 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
         }
     }
     bool pass_through = false;
+    bool has_phase = false; // MEDIA: the vertex is a scattering event inside the medium
+    float phase_g = 0.f;
+    uint32_t med_in = VMK_INVALID, med_out = VMK_INVALID; // MediumInterface of the vertex
     if (active && found) {
         compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
         it.wo = normalize(-ps.ray.d);
-        if (it.mat_id == VMK_INVALID) { // integrator.cpp:208-214: pass through, bounce not counted
+        if constexpr (MEDIA) {
+            med_in = S.instances[hit.inst].inside_medium; med_out = S.instances[hit.inst].outside_medium; // geometry.cpp:90
+            ps.ray.t_max = length(it.pos - ps.ray.o) / length(ps.ray.d);                                   // geometry.h:64-69
+            if (P->process_mediums && ps.medium != VMK_INVALID) { // HomogeneousMedium::sample, 2 draws (integrator.cpp:199-206)
+                const vmk_medium *m = S.mediums + ps.medium;
+                V3 sigma_t = medium_sigma_t(m), sigma_s = medium_sigma_s(m);
+                uint32_t channel = (uint32_t) (sampler.next_1d() * 3.f); if (channel > 2u) channel = 2u;
+                float st_c = channel == 0 ? sigma_t.x : (channel == 1 ? sigma_t.y : sigma_t.z);
+                float dist = -log_(1.f - sampler.next_1d()) / st_c;
+                float t = fmin_(dist / length(ps.ray.d), ps.ray.t_max);
+                bool sampled_medium = t < ps.ray.t_max;
+                if (sampled_medium) { // Interaction(ray->at(t), -ray->direction(), true), init_phase, set_medium
+                    it.pos = ps.ray.o + ps.ray.d * t; it.wo = -1.f * ps.ray.d; it.ng = mk3(0.f); it.uv = {0.f, 0.f};
+                    it.mat_id = VMK_INVALID; it.light_id = VMK_INVALID; it.prim_id = VMK_INVALID; it.prim_area = 0.f;
+                    has_phase = true; phase_g = m->g; med_in = ps.medium; med_out = ps.medium;
+                }
+                V3 tr = medium_Tr(m, t);
+                V3 density = sampled_medium ? sigma_t * tr : tr;
+                float pdf = (density.x + density.y + density.z) / 3.f;
+                ps.T *= sampled_medium ? tr * sigma_s / pdf : tr / pdf;
+            }
+        }
+        if (it.mat_id == VMK_INVALID && !has_phase) { // integrator.cpp:208-214: pass through, bounce not counted
+            if constexpr (MEDIA) ps.medium = P->process_mediums ? (dot(it.ng, ps.ray.d) > 0.f ? med_out : med_in) : VMK_INVALID;
             ps.ray = spawn_ray(it.pos, it.ng, ps.ray.d);
             pass_through = true;
         } else {
-            cnt.hits++;
+            if (!has_phase) cnt.hits++;
             if (it.light_id != VMK_INVALID) { // integrator.cpp:221-231
                 LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt);
                 float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
                 weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
-                ps.L += ev.L * ps.T * weight * 1.f;
+                V3 tr = mk3(1.f);
+                if constexpr (MEDIA) tr = geometry_Tr(S, P, ps.ray, ps.medium);
+                ps.L += ev.L * ps.T * weight * tr;
             }
             ps.prev_ng = it.ng;
             // NEE (3 draws) + shadow ray
@@ -272,12 +331,22 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
     Hit sh;
     bool occluded = traverse_wave(S, shadow_ray, shade, true, ws, sh, cnt);
     if (!shade) return !pass_through;
-    // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
-    MatCtx mc;
-    mat_prepare<FULL>(S, S.materials + it.mat_id, it, mc, cnt);
+    V3 tr_shadow = mk3(1.f);
+    if constexpr (MEDIA) tr_shadow = geometry_Tr(S, P, shadow_ray, P->process_mediums ? (dot(it.ng, shadow_ray.d) > 0.f ? med_out : med_in) : VMK_INVALID);
     V3 wi = normalize(ls.p_light - it.pos);
     ScatterEval se; BSDFSample bs;
-    mat_evaluate_and_sample<FULL>(S, mc, it, wi, sampler, se, bs, cnt);
+    if (MEDIA && has_phase) { // integrator.cpp:271-279: the phase function stands in for the BSDF (2 draws)
+        float f = phase_HG(dot(it.wo, wi), phase_g);
+        se.f = mk3(f); se.pdf = f; se.flags = 0;
+        float fs;
+        bs.wi = hg_sample(it.wo, phase_g, sampler, &fs);
+        bs.eval.f = mk3(fs); bs.eval.pdf = fs; bs.eval.flags = 0; bs.eta = 1.f;
+    } else {
+        // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
+        MatCtx mc;
+        mat_prepare<FULL>(S, S.materials + it.mat_id, it, mc, cnt);
+        mat_evaluate_and_sample<FULL>(S, mc, it, wi, sampler, se, bs, cnt);
+    }
     if (dbg) {
         dbg[4] = ls.eval.pdf; dbg[5] = se.pdf; dbg[6] = bs.eval.pdf; dbg[7] = occluded ? 1.f : 0.f;
         dbg[8] = shadow_ray.o.x; dbg[9] = shadow_ray.o.y; dbg[10] = shadow_ray.o.z; dbg[11] = shadow_ray.d.x; dbg[12] = shadow_ray.d.y;
@@ -289,7 +358,7 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
     V3 Ld = mk3(0.f);
     if (!occluded && se.pdf > 0.f && ls.eval.pdf > 0.f) Ld = ls.eval.L * se.f * weight / ls.eval.pdf;
     if (mis_mode == 2) Ld = Ld * 0.f;
-    ps.L += ps.T * Ld * 1.f;
+    ps.L += ps.T * Ld * tr_shadow;
     ps.eta_scale *= sqr(bs.eta);
     float lum = max_comp(ps.T);
     if (!(bs.eval.pdf > 0.f) || lum == 0.f) return true;
@@ -301,6 +370,7 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
         ps.T = ps.T / q;
     }
     ps.scatter_pdf = bs.eval.pdf;
+    if constexpr (MEDIA) ps.medium = P->process_mediums ? (dot(it.ng, bs.wi) > 0.f ? med_out : med_in) : VMK_INVALID; // interaction.cpp:114-123
     ps.ray = spawn_ray(it.pos, it.ng, bs.wi);
     ++ps.bounces;
     return ps.bounces >= max_depth;
@@ -345,7 +415,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderArgs &A, uint32_t slot
     return *px < width && *py < height;
 }
 
-template<bool FULL>
+template<bool FULL, bool MEDIA>
 __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = *A.scene;
@@ -363,7 +433,7 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
     Sampler sampler; sampler.state = 0;
     PathState ps;
     ps.ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
-    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.prev_ng = mk3(0.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.bounces = 0;
+    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.prev_ng = mk3(0.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.bounces = 0; ps.medium = VMK_INVALID;
 
     for (;;) {
         // ---- hand new paths to idle lanes: ballot + prefix inside the wave, one atomic per chunk ----
@@ -386,7 +456,7 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
                         sampler.start(px, py, frame, 0);
                         ps.ray = generate_ray(P, px, py, sampler);
                         sampler.start(px, py, frame, 1); // path_tracing kernel, integrator.cpp:93
-                        path_begin(ps);
+                        path_begin(ps, P);
                         has_path = true; item = w;
                         cnt.paths++;
                     }
@@ -398,7 +468,7 @@ __global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArg
 
         // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
         // (all lanes take part: the traversals inside are wave-cooperative; lanes without a path contribute no ray)
-        bool terminate = path_bounce<FULL>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
+        bool terminate = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
         if (has_path && terminate) {
             A.stage[item] = make_float4(ps.L.x, ps.L.y, ps.L.z, 1.f);
             has_path = false;
@@ -486,6 +556,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
         case 1: {
             float s, c; sincos_(a[0], &s, &c);
             o[0] = s; o[1] = c; o[2] = acos_(clamp_(a[0], -1.f, 1.f)); o[3] = atan2_(a[1], a[0]); o[4] = exp_(-abs_(a[0])); o[5] = sqrt_(abs_(a[0]));
+            if (out_stride >= 7) o[6] = log_(abs_(a[0]) * 0.125f + 5.9604645e-8f);
             break;
         }
         case 2: {
@@ -531,11 +602,11 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             Sampler smp; smp.start(px, py, frame, 0);
             PathState ps; ps.ray = generate_ray(P, px, py, smp);
             smp.start(px, py, frame, 1);
-            path_begin(ps);
+            path_begin(ps, P);
             bool alive = live;
             for (int v = 0; v < 64 && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
                 float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                bool end = path_bounce<true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                bool end = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
                 if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
                 if (end) alive = false;
             }
@@ -549,13 +620,13 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             Sampler smp; smp.start(px, py, frame, 0);
             PathState ps; ps.ray = generate_ray(P, px, py, smp);
             smp.start(px, py, frame, 1);
-            path_begin(ps);
+            path_begin(ps, P);
             int nv = 0;
             bool alive = live && P->max_depth > 0;
             for (int v = 0; v < 64 && __any(alive); ++v) {
                 float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 Ray r = ps.ray;
-                bool end = path_bounce<true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                bool end = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
                 if (alive && v < 24) {
                     float *q = o + 1 + v * 16;
                     q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = r.t_max; q[7] = 1.f;
@@ -569,6 +640,68 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
         }
         default: break;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Albedo-table precompute (the reference's `vision-precompute` app, apps/precompute/main.cpp:24-41):
+// Material::precompute_lobe (material.h:121-163) — texel (x, y, z) of a res^3 (res^2 for table 0) grid, ratio =
+// idx / (res - 1), sampler.start((x, y), 0, 0), Lobe::precompute_with_radio + integral_albedo (lobe.cpp:13-33) in
+// Importance mode, no energy compensation while measuring.  One lane integrates one texel with its own sequential
+// RNG stream, exactly like the reference's kernel, accumulating in f64.
+// which: 0 PureReflection (mirror.cpp:53-57, lobe.h:344-356), 1 Dielectric, 2 DielectricInv (glass.cpp:14-76),
+//        3 Specular (principled_bsdf.cpp:177-190), 4 Coat (principled_bsdf.cpp:135-146)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_albedo(uint32_t which, uint32_t res, uint32_t sample_num, float *out) {
+    const uint32_t depth = which == 0 ? 1u : res, nc = (which == 1 || which == 2) ? 2u : 1u;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= res * res * depth) return;
+    uint32_t x = i % res, y = (i / res) % res, z = i / (res * res);
+    Sampler sampler; sampler.start(x, y, 0, 0);
+    float rx = (float) x / (float) (res - 1), ry = (float) y / (float) (res - 1), rz = which == 0 ? 0.f : (float) z / (float) (res - 1);
+    Lobe l;
+    l.kind = LB_MICROFACET; l.kr = mk3(1.f); l.rs = mk3(0.f); l.A = 0.f; l.B = 0.f; l.compensate = false; l.weight = 1.f; l.sample_weight = 1.f;
+    l.fr.kind = FR_CONSTANT; l.fr.a = mk3(0.f); l.fr.b = mk3(0.f); l.fr.eta = 1.f;
+    float a = clamp_(sqr(rx), 0.001f, 1.f); // from_ratio_x lobe.cpp:183-185 / glass.cpp:36-40
+    l.ax = l.ay = a;
+    float cos_t = clamp_(ry, 1e-4f, 1.0f);   // from_ratio_y lobe.cpp:158-164
+    V3 wo = mk3(sqrt_(1.f - sqr(cos_t)), 0.f, cos_t);
+    switch (which) {
+        case 0: break;
+        case 1: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 5.f); break;
+        case 2: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = rcp(lerp_(rz, 1.003f, 5.f)); break;
+        case 3: l.fr.kind = FR_SCHLICK; l.fr.a = mk3(0.04f); l.fr.eta = schlick_ior_from_F0(pow4(rz)); break;
+        default: l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 4.f); break;
+    }
+    DScene none{}; // the lobes measured here never touch the scene (compensate == false)
+    double acc0 = 0.0, acc1 = 0.0;
+    for (uint32_t k = 0; k < sample_num; ++k) {
+        bool valid = true;
+        V3 wi = sample_wi_local(l, wo, sampler, &valid);
+        ScatterEval se; se.f = mk3(0.f); se.pdf = 0.f; se.flags = flag::Unset;
+        if (l.kind == LB_DIELECTRIC) { // DielectricPrecompute::compensate() == false (glass.cpp:17), Importance mode
+            bool refl = same_hemisphere(wo, wi);
+            float eta = l.fr.eta, eta_p = refl ? 1.f : eta;
+            V3 wh = face_forward(normalize(wo + wi * eta_p), wo);
+            V3 F = l.fr.evaluate(abs_dot(wh, wo));
+            if (refl) { se.f = F * BRDF_div_fr(wo, wh, wi, l.ax, l.ay); se.pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay) * dielectric_refl_prob(l, F); }
+            else {
+                V3 wh2 = normalize(wo + wi * eta);
+                se.f = ((1.f - F) * BTDF_div_ft(wo, wh2, wi, eta, l.ax, l.ay, false)) * l.kr;
+                se.pdf = PDF_wi_transmission(wo, face_forward(wh, wo), wi, eta, l.ax, l.ay) * (1.f - dielectric_refl_prob(l, F));
+            }
+        } else {
+            float eta_dummy;
+            se = eval_local(none, l, wo, wi, &eta_dummy);
+        }
+        se.pdf *= valid ? 1.f : 0.f;
+        if (se.pdf > 0.f) {
+            float r = (se.f.x / se.pdf) * abs_cos_theta(wi);
+            acc0 += (double) r;
+            if (same_hemisphere(wi, wo)) acc1 += (double) r;
+        }
+    }
+    out[(size_t) i * nc] = (float) (acc0 / sample_num);
+    if (nc == 2) out[(size_t) i * nc + 1] = (float) (acc1 / sample_num);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -603,6 +736,8 @@ struct vmk_ctx {
     DevBuf<vmk_instance> instances;
     DevBuf<vmk_material> materials;
     DevBuf<vmk_light> lights;
+    DevBuf<vmk_medium> mediums;
+    uint32_t n_mediums{0};
     DevBuf<vmk_texture> textures;
     DevBuf<uint8_t> tex_data;
     DevBuf<float> alias_prob, alias_func, srgb_lut, luts;
@@ -659,7 +794,7 @@ void vmk_destroy(vmk_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     ctx->tri_pos_in.release(); ctx->tri_pos.release(); ctx->tri_attr_in.release(); ctx->tri_attr.release(); ctx->tri_lookup.release();
-    ctx->instances.release(); ctx->materials.release(); ctx->lights.release(); ctx->textures.release(); ctx->tex_data.release();
+    ctx->instances.release(); ctx->materials.release(); ctx->lights.release(); ctx->mediums.release(); ctx->textures.release(); ctx->tex_data.release();
     ctx->alias_prob.release(); ctx->alias_func.release(); ctx->alias_idx.release(); ctx->srgb_lut.release(); ctx->luts.release();
     ctx->nodes.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release(); ctx->stage.release();
     ctx->queue.release(); ctx->counters.release();
@@ -708,6 +843,11 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
             if (l.res_x == 0 || l.res_y == 0 || l.alias_count != l.res_y || (uint64_t) l.alias_offset + l.alias_count > sc->n_alias || (uint64_t) l.cond_offset + (uint64_t) l.res_x * l.res_y > sc->n_alias) { ctx->error = "vmk_upload_scene: environment light tables inconsistent"; return VMK_ERR_ARG; }
         } else { ctx->error = "vmk_upload_scene: unknown light type"; return VMK_ERR_ARG; }
     }
+    if (sc->n_mediums && !sc->mediums) { ctx->error = "vmk_upload_scene: mediums missing"; return VMK_ERR_ARG; }
+    for (uint32_t i = 0; i < sc->n_instances; ++i) {
+        const vmk_instance &in = sc->instances[i];
+        if ((in.inside_medium != VMK_INVALID && in.inside_medium >= sc->n_mediums) || (in.outside_medium != VMK_INVALID && in.outside_medium >= sc->n_mediums)) { ctx->error = "vmk_upload_scene: instance medium id out of range"; return VMK_ERR_ARG; }
+    }
     for (uint32_t i = 0; i < sc->n_alias; ++i) if (sc->alias_idx[i] >= sc->n_alias) { ctx->error = "vmk_upload_scene: alias index out of range"; return VMK_ERR_ARG; }
     if (sc->env_light != VMK_INVALID && (sc->env_light >= sc->n_lights || sc->lights[sc->env_light].type != VMK_LIGHT_SPHERICAL)) { ctx->error = "vmk_upload_scene: env_light is not a spherical light"; return VMK_ERR_ARG; }
     if (!sc->luts.pure_reflection || !sc->luts.dielectric || !sc->luts.dielectric_inv || !sc->luts.specular || !sc->luts.coat) { ctx->error = "vmk_upload_scene: albedo tables missing"; return VMK_ERR_ARG; }
@@ -723,6 +863,8 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     HIP_TRY(ctx->instances.upload(sc->instances, sc->n_instances, st));
     HIP_TRY(ctx->materials.upload(sc->materials, sc->n_materials, st));
     HIP_TRY(ctx->lights.upload(sc->lights, sc->n_lights, st));
+    HIP_TRY(ctx->mediums.upload(sc->mediums, sc->n_mediums, st));
+    ctx->n_mediums = sc->n_mediums;
     HIP_TRY(ctx->textures.upload(sc->textures, sc->n_textures, st));
     HIP_TRY(ctx->tex_data.upload(sc->tex_data, (size_t) sc->tex_bytes, st));
     HIP_TRY(ctx->alias_prob.upload(sc->alias_prob, sc->n_alias, st));
@@ -737,7 +879,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     for (int i = 0; i < 6; ++i) { off[i] = o; if (src[i]) HIP_TRY(hipMemcpyAsync(ctx->luts.p + o, src[i], sizes[i] * 4, hipMemcpyHostToDevice, st)); o += sizes[i]; }
     DScene &h = ctx->h_scene;
     h = DScene{};
-    h.instances = ctx->instances.p; h.materials = ctx->materials.p; h.lights = ctx->lights.p; h.textures = ctx->textures.p; h.tex_data = ctx->tex_data.p;
+    h.instances = ctx->instances.p; h.materials = ctx->materials.p; h.lights = ctx->lights.p; h.mediums = ctx->mediums.p; h.textures = ctx->textures.p; h.tex_data = ctx->tex_data.p;
     h.alias_prob = ctx->alias_prob.p; h.alias_idx = ctx->alias_idx.p; h.alias_func = ctx->alias_func.p; h.srgb_lut = ctx->srgb_lut.p;
     h.lut_pure_reflection = ctx->luts.p + off[0]; h.lut_dielectric = ctx->luts.p + off[1]; h.lut_dielectric_inv = ctx->luts.p + off[2];
     h.lut_specular = ctx->luts.p + off[3]; h.lut_coat = ctx->luts.p + off[4]; h.lut_sheen_approx = src[5] ? ctx->luts.p + off[5] : nullptr;
@@ -920,6 +1062,7 @@ int vmk_reset_accum(vmk_ctx *ctx) {
 int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, const vmk_tiles *tiles, float *kernel_ms) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready || !ctx->fb) { ctx->error = "vmk_render_batch: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    if (ctx->params.process_mediums && ctx->params.camera_medium != VMK_INVALID && ctx->params.camera_medium >= ctx->n_mediums) { ctx->error = "vmk_render_batch: camera medium out of range"; return VMK_ERR_ARG; }
     if (kernel_ms) *kernel_ms = 0.f;
     if (frame_count == 0) return VMK_OK;
     RenderArgs A{};
@@ -947,7 +1090,8 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     if (ctx->stage.n < (size_t) per_launch * n_slots) HIP_TRY(ctx->stage.alloc((size_t) per_launch * n_slots));
     A.stage = ctx->stage.p;
     int per_cu = 0;
-    auto kernel = ctx->full_materials ? k_render<true> : k_render<false>;
+    const bool media = ctx->params.process_mediums != 0;
+    auto kernel = ctx->full_materials ? (media ? k_render<true, true> : k_render<true, false>) : (media ? k_render<false, true> : k_render<false, false>);
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
     if (kernel_ms) HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
@@ -1051,6 +1195,24 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     return VMK_OK;
 }
 
+int vmk_precompute_albedo(vmk_ctx *ctx, uint32_t which, uint32_t res, uint32_t sample_num, float *out) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (which > 4 || res < 2 || res > 128 || sample_num == 0 || !out) { ctx->error = "vmk_precompute_albedo: bad argument"; return VMK_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t texels = (size_t) res * res * (which == 0 ? 1 : res), n = texels * ((which == 1 || which == 2) ? 2 : 1);
+    DevBuf<float> d;
+    hipError_t e = d.alloc(n);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_albedo, dim3((unsigned) ((texels + 63) / 64)), dim3(64), 0, ctx->stream, which, res, sample_num, d.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (e != hipSuccess) { ctx->error = std::string("vmk_precompute_albedo: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    return VMK_OK;
+}
+
 int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
     if (!ctx) return VMK_ERR_ARG;
     if (!n || !in || !out || !in_stride || !out_stride || kind > 7) { ctx->error = "vmk_test_eval: bad argument"; return VMK_ERR_ARG; }
@@ -1058,6 +1220,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     if (in_stride < min_in[kind] || out_stride < min_out[kind]) { ctx->error = "vmk_test_eval: stride too small for this kind"; return VMK_ERR_ARG; }
     if (kind == 4 && !ctx->accel_ready) { ctx->error = "vmk_test_eval: kind 4 needs an uploaded scene + accel"; return VMK_ERR_STATE; }
     if ((kind == 6 || kind == 7) && (!ctx->accel_ready || !ctx->params_ready)) { ctx->error = "vmk_test_eval: kinds 6/7 need scene, accel and render params"; return VMK_ERR_STATE; }
+    if ((kind == 6 || kind == 7) && ctx->params.process_mediums && ctx->params.camera_medium != VMK_INVALID && ctx->params.camera_medium >= ctx->n_mediums) { ctx->error = "vmk_test_eval: camera medium out of range"; return VMK_ERR_ARG; }
     if (kind == 5 && !ctx->params_ready) { ctx->error = "vmk_test_eval: kind 5 needs render params"; return VMK_ERR_STATE; }
     if (kind == 4) { // material ids are validated here: the kernel indexes materials[] with them
         uint32_t n_mat = (uint32_t) ctx->materials.n;

@@ -248,6 +248,8 @@ struct HostScene {
     std::vector<vmk_instance> instances;
     std::vector<vmk_material> materials;
     std::vector<std::string> material_names;
+    std::vector<vmk_medium> mediums;
+    std::vector<std::string> medium_names;
     std::vector<vmk_light> lights;
     std::vector<vmk_texture> textures;
     std::vector<uint8_t> tex_data;
@@ -517,9 +519,10 @@ struct HostScene {
     static void apply_point(const float *o2w, const float *p, float *out) {
         for (int r = 0; r < 3; ++r) out[r] = o2w[0 * 4 + r] * p[0] + o2w[1 * 4 + r] * p[1] + o2w[2 * 4 + r] * p[2] + o2w[3 * 4 + r];
     }
-    uint32_t add_instance(const Mesh &mesh, const Mat4 &o2w, uint32_t mat_id) {
+    uint32_t add_instance(const Mesh &mesh, const Mat4 &o2w, uint32_t mat_id, uint32_t inside_medium, uint32_t outside_medium) {
         vmk_instance inst{};
         inst.mat_id = mat_id; inst.light_id = VMK_INVALID;
+        inst.inside_medium = inside_medium; inst.outside_medium = outside_medium;
         inst.tri_offset = (uint32_t) tri_pos.size(); inst.tri_count = (uint32_t) (mesh.idx.size() / 3);
         for (int i = 0; i < 16; ++i) inst.o2w[i] = (float) o2w.m[i];
         Mat4 inv = inverse(o2w); // normal matrix = transpose(inverse(M3x3)): n2w(row r, col c) = inv(c, r)
@@ -573,7 +576,36 @@ struct HostScene {
         if (spec_type != "srgb") fail("spectrum/" + spec_type + " is a §8(f) 'next' row (needs the stripped srgb2spec table); only spectrum/srgb is in scope");
         if (spec["param"]["dimension"].as_uint(3) != 3) fail("spectrum/srgb requires dimension 3");
         describe("spectrum", "srgb", "");
-        if (root["mediums"]["process"].as_bool(false)) describe("medium", "ignored", "mediums.process=true is a §8(f) 'next' row; rendered as the non-fog variant");
+        // mediums (scene_desc.cpp:26-35, MediumDesc::init node_desc.cpp:182-197, homogeneous.cpp:20-24)
+        uint32_t global_medium = VMK_INVALID;
+        params.process_mediums = 0; params.camera_medium = VMK_INVALID;
+        if (root.contains("mediums")) {
+            const Json &md = root["mediums"];
+            bool process = md["process"].as_bool(true);
+            if (!opt.mediums) { if (process && md["list"].size()) describe("medium", "ignored", "vmk_host_options.mediums == 0: rendered as the non-fog variant"); }
+            else if (process) {
+                for (auto &m : md["list"].arr) {
+                    std::string type = m["type"].as_string("homogeneous");
+                    if (type != "homogeneous") fail("medium/" + type + " is outside the hot-path scope (homogeneous)");
+                    const Json &mp = m["param"];
+                    if (!mp["medium_name"].as_string("").empty()) fail("medium: measured 'medium_name' tables are outside the hot-path scope");
+                    vmk_medium vm{};
+                    auto read3 = [&](const Json &j, float *out) { // SlotDesc: scalar -> broadcast, array -> value
+                        const Json &v = j.contains("value") ? j["value"] : j;
+                        if (v.is_array()) for (int k = 0; k < 3; ++k) out[k] = v.at(std::min<size_t>(k, v.size() - 1)).as_float(0.f);
+                        else for (int k = 0; k < 3; ++k) out[k] = v.as_float(0.f);
+                    };
+                    read3(mp["sigma_a"], vm.sigma_a); read3(mp["sigma_s"], vm.sigma_s);
+                    float g = mp["g"].contains("value") ? mp["g"]["value"].as_float(0.f) : mp["g"].as_float(0.f);
+                    vm.g = std::min(0.99f, std::max(-0.99f, g));
+                    vm.scale = mp["scale"].contains("value") ? mp["scale"]["value"].as_float(1.f) : mp["scale"].as_float(1.f);
+                    mediums.push_back(vm); medium_names.push_back(m["name"].as_string());
+                    describe("medium", "homogeneous", m["name"].as_string());
+                }
+                params.process_mediums = mediums.empty() ? 0u : 1u;
+                global_medium = medium_id(md["global"].as_string(""));
+            }
+        }
 
         // ---- materials ----
         for (auto &md : root["materials"].arr) add_material(md);
@@ -626,7 +658,11 @@ struct HostScene {
             std::string mat_name = p["material"].as_string();
             uint32_t mat_id = VMK_INVALID;
             for (uint32_t i = 0; i < material_names.size(); ++i) if (material_names[i] == mat_name) { mat_id = i; break; } // find_if: first match
-            uint32_t inst_id = add_instance(mesh, parse_transform(p["transform"]), mat_id);
+            // ShapeGroup::post_init shape.cpp:246-271: explicit {inside, outside} names or the global medium on both sides
+            uint32_t m_in = global_medium, m_out = global_medium;
+            if (params.process_mediums && p.contains("medium")) { m_in = medium_id(p["medium"]["inside"].as_string("")); m_out = medium_id(p["medium"]["outside"].as_string("")); }
+            if (!params.process_mediums) m_in = m_out = VMK_INVALID;
+            uint32_t inst_id = add_instance(mesh, parse_transform(p["transform"]), mat_id, m_in, m_out);
             if (p.contains("emission")) { // ShapeDesc::init node_desc.cpp:66-68 -> light/area with inst_id
                 const Json &em = p["emission"];
                 std::string etype = em["type"].as_string("area");
@@ -706,6 +742,7 @@ struct HostScene {
         if (cam_type != "thin_lens" && cam_type != "pinhole") fail("sensor/" + cam_type + " is outside the hot-path scope");
         describe("sensor", cam_type, cam["param"]["name"].as_string());
         const Json &cp = cam["param"];
+        if (params.process_mediums) params.camera_medium = cp.contains("medium") ? medium_id(cp["medium"].as_string("")) : global_medium; // photosensory.cpp:16-32
         const Json &fbp = root["pipeline"]["param"]["frame_buffer"]["param"];
         uint32_t W = 1280, H = 720; // frame_buffer.cpp:18 default
         if (fbp["resolution"].is_array() && fbp["resolution"].size() == 2) { W = fbp["resolution"].at(0).as_uint(W); H = fbp["resolution"].at(1).as_uint(H); }
@@ -813,8 +850,14 @@ struct HostScene {
         for (int i = 0; i < 5; ++i) if (!*dst[i]) fail("albedo-table blob lacks a required table");
     }
 
+    uint32_t medium_id(const std::string &name) const {
+        for (uint32_t i = 0; i < medium_names.size(); ++i) if (medium_names[i] == name) return i;
+        return VMK_INVALID;
+    }
+
     void finalize() {
         scene.abi_version = VMK_ABI_VERSION;
+        scene.n_mediums = (uint32_t) mediums.size(); scene.mediums = mediums.data();
         scene.n_tris = (uint32_t) tri_pos.size(); scene.n_instances = (uint32_t) instances.size(); scene.n_materials = (uint32_t) materials.size();
         scene.n_lights = (uint32_t) lights.size(); scene.n_textures = (uint32_t) textures.size(); scene.n_alias = (uint32_t) alias_prob.size();
         scene.tri_pos = tri_pos.data(); scene.tri_attr = tri_attr.data(); scene.instances = instances.data(); scene.materials = materials.data();
