@@ -95,7 +95,9 @@ typedef struct vmk_material {
 
 typedef enum vmk_light_type {
     VMK_LIGHT_AREA = 0,     /* "area"      render_core/light/area.cpp */
-    VMK_LIGHT_SPHERICAL = 1 /* "spherical" render_core/light/environments/spherical.cpp */
+    VMK_LIGHT_SPHERICAL = 1, /* "spherical" render_core/light/environments/spherical.cpp */
+    VMK_LIGHT_POINT = 2,    /* "point"     render_core/light/point.cpp:19-48; IPointLight light.h:222-251, light.cpp:49-58 */
+    VMK_LIGHT_SPOT = 3      /* "spot"      render_core/light/spot.cpp:19-80 */
 } vmk_light_type;
 
 typedef struct vmk_light {
@@ -112,6 +114,10 @@ typedef struct vmk_light {
     float w2o[9];          /* env: 3x3 of w2o_  (spherical.cpp:36-44), column-major */
     float o2w[9];          /* env: 3x3 of inverse(w2o_) as evaluated by the reference per sample (spherical.cpp:114) */
     float world_diameter;  /* env: Scene::world_diameter() (scene.h:108-109) */
+    float position[3];     /* point / spot */
+    float direction[3];    /* spot: normalised axis */
+    float cos_angle;       /* spot: cos(angle), angle clamped to [1, 89] degrees (spot.cpp:30) */
+    float cos_falloff_start; /* spot: cos(max(0, angle - falloff)) (spot.cpp:57-59) */
 } vmk_light;
 
 /* ---- geometry -------------------------------------------------------------------------------- */

@@ -1133,13 +1133,35 @@ inline LightSample env_sample_wi(const vmk_scene *s, const vmk_light &l, const L
     ret.p_light = p_ref.pos + world_dir * l.world_diameter;
     return ret;
 }
+// IPointLight::sample_wi (light.cpp:49-58) with PointLight::Le (point.cpp:43-48) / SpotLight::Le + falloff (spot.cpp:56-79);
+// PDF_wi = -1 marks a delta light (light.h:227-231)
+inline LightSample point_sample_wi(const vmk_scene *s, const vmk_light &l, const LightSampleContext &p_ref) {
+    LightSample ls;
+    float3 pos = ld3(l.position);
+    float3 w_un = p_ref.pos - pos;
+    float3 value = eval_slot3(s, l.color, make_float2(0.f, 0.f)) * l.scale;
+    if (l.type == VMK_LIGHT_SPOT) {
+        float3 w = normalize(w_un);
+        float cos_theta = clamp_(dot(ld3(l.direction), w), l.cos_angle, l.cos_falloff_start);
+        float factor = (cos_theta - l.cos_angle) / (l.cos_falloff_start - l.cos_angle);
+        ls.eval.L = value / length_squared(w_un) * pow4(factor);
+    } else ls.eval.L = value / length_squared(w_un);
+    ls.eval.pdf = -1.f;
+    ls.p_light = pos;
+    return ls;
+}
 inline LightSample light_sample_wi(const LightCtx &c, const LightSampleContext &lsc, Sampler &sampler) { // lightsampler.cpp:199-216
     float u_light = sampler.next_1d();
     float2 u_surface = sampler.next_2d();
     uint32_t index; float pmf;
     light_select(c, u_light, &index, &pmf);
     const vmk_light &l = c.s->lights[index];
-    LightSample ls = l.type == VMK_LIGHT_AREA ? area_sample_wi(c, l, lsc, u_surface) : env_sample_wi(c.s, l, lsc, u_surface);
+    LightSample ls;
+    switch (l.type) {
+        case VMK_LIGHT_AREA: ls = area_sample_wi(c, l, lsc, u_surface); break;
+        case VMK_LIGHT_SPHERICAL: ls = env_sample_wi(c.s, l, lsc, u_surface); break;
+        default: ls = point_sample_wi(c.s, l, lsc); break; // point / spot (u_surface unused, light.cpp:49-58)
+    }
     ls.eval.pdf *= pmf;
     return ls;
 }

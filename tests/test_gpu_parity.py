@@ -99,6 +99,8 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("classroom", "scenes/classroom/vision_scene.json", 48, 27, 2),
     ("cbox_media", "scenes/cbox/cbox_media.json", 32, 32, 4),          # homogeneous media + HG phase function (§8f-1)
     ("classroom_fog", "scenes/classroom/vision_scene.json", 48, 27, 2),  # the scene as shipped: global fog
+    ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4),         # point + spot lights, mitchell filter (§8f-2)
+    ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),             # point light, Lanczos-sinc filter
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog"))

@@ -102,7 +102,8 @@ def test_json_comments_and_defaults(built, tmp_path):
     (lambda s: s["materials"].append({"type": "subsurface", "name": "x", "param": {}}), "material type 'subsurface'"),
     (lambda s: s["integrator"].update(type="rt"), "integrator/rt"),
     (lambda s: s["spectrum"].update(type="hero"), "spectrum/hero"),
-    (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "point", "param": {}}), "light/point"),
+    (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "projector", "param": {}}), "light/projector"),
+    (lambda s: s["camera"]["param"].update(filter={"type": "blackman", "param": {"radius": 1}}), "filter/blackman"),
     (lambda s: s["shapes"].append({"type": "sphere", "name": "s", "param": {}}), "shape/sphere"),
     (lambda s: s["shapes"][-1]["param"].pop("emission"), "no light"),
 ])
@@ -127,3 +128,27 @@ def test_obj_loader_fan_triangulation_and_flip_uv(built, tmp_path):
     assert list(t0.p2) == [1, 1, 0] and list(t1.p1) == [1, 1, 0] and list(t1.p2) == [0, 1, 0]
     assert abs(s.tri_attr[36].uv2[1] - 0.75) < 1e-7   # flip_uv default true: v -> 1 - v (model.cpp:30-34)
     assert list(s.tri_attr[36].n0) == [0, 0, 1]
+
+
+def test_point_spot_lights_and_fitted_filters(built):
+    """light/point, light/spot (point.cpp, spot.cpp) and filter/mitchell, filter/sinc (fitted_curve.h) reach the tables."""
+    import math
+    from vision_amd import _abi
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_lights.json"), width=16, height=16)
+    sc = hs.scene
+    types = [sc.lights[i].type for i in range(sc.n_lights)]
+    assert sorted(types) == [0, 2, 3]  # area (the ceiling quad), point, spot
+    spot = [sc.lights[i] for i in range(sc.n_lights) if sc.lights[i].type == 3][0]
+    assert abs(spot.cos_angle - math.cos(math.radians(20))) < 1e-6
+    # spot.cpp:31 clamps the falloff in DEGREES against the angle in RADIANS before converting: min(2, 0.349) deg
+    assert abs(spot.cos_falloff_start - math.cos(math.radians(20) - math.radians(math.radians(20)))) < 1e-6
+    assert abs(sum(d * d for d in spot.direction) - 1.0) < 1e-6
+    point = [sc.lights[i] for i in range(sc.n_lights) if sc.lights[i].type == 2][0]
+    assert list(point.position) == pytest.approx([-0.5, 1.8, 0.0]) and point.scale == pytest.approx(0.2)
+    assert hs.params.filter_type == 2  # fitted-curve table
+    m = list(hs.params.filter_marginal_func)
+    assert all(v >= 0 for v in m) and m[0] > m[-1]  # |mitchell| is largest at the centre
+    hs2 = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_sinc.json"), width=16, height=16)
+    c = np.array(hs2.params.filter_cond_func, np.float32).reshape(20, 20)
+    # windowed sinc with radius 1.5 crosses zero at |x| = 1: the tabulated |f| dips there (column 13 ~ x = 1.0125)
+    assert c[0, 13] < c[0, 10] and c[0, 13] < c[0, 16]

@@ -21,7 +21,8 @@ class Material(C.Structure):
 class Light(C.Structure):
     _fields_ = [("type", u32), ("inst_id", u32), ("two_sided", u32), ("scale", f32), ("color", Slot),
                 ("alias_offset", u32), ("alias_count", u32), ("alias_integral", f32), ("cond_offset", u32),
-                ("res_x", u32), ("res_y", u32), ("w2o", f32 * 9), ("o2w", f32 * 9), ("world_diameter", f32)]
+                ("res_x", u32), ("res_y", u32), ("w2o", f32 * 9), ("o2w", f32 * 9), ("world_diameter", f32),
+                ("position", f32 * 3), ("direction", f32 * 3), ("cos_angle", f32), ("cos_falloff_start", f32)]
 
 
 class TriPos(C.Structure):

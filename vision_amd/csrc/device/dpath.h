@@ -955,13 +955,32 @@ VD LightSample env_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, V2 u
     ret.p_light = p_ref + world_dir * l->world_diameter;
     return ret;
 }
+// IPointLight::sample_wi (light.cpp:49-58) with PointLight::Le (point.cpp:43-48) / SpotLight::Le + falloff (spot.cpp:56-79);
+// PDF_wi = -1 marks a delta light (light.h:227-231)
+VD LightSample point_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, DCounters &cnt) {
+    LightSample ls;
+    V3 pos = ld3(l->position);
+    V3 w_un = p_ref - pos;
+    V3 value = eval_slot3(S, l->color, V2{0.f, 0.f}, cnt) * l->scale;
+    if (l->type == VMK_LIGHT_SPOT) {
+        V3 w = normalize(w_un);
+        float cos_theta = clamp_(dot(ld3(l->direction), w), l->cos_angle, l->cos_falloff_start);
+        float factor = (cos_theta - l->cos_angle) / (l->cos_falloff_start - l->cos_angle);
+        ls.eval.L = value / length_squared(w_un) * pow4(factor);
+    } else ls.eval.L = value / length_squared(w_un);
+    ls.eval.pdf = -1.f;
+    ls.p_light = pos;
+    return ls;
+}
 VD LightSample light_sample_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, Sampler &sampler, DCounters &cnt) { // lightsampler.cpp:199-216
     float u_light = sampler.next_1d();
     V2 u_surface = sampler.next_2d();
     uint32_t index; float pmf;
     light_select(S, P, u_light, &index, &pmf);
     const vmk_light *l = S.lights + index;
-    LightSample ls = l->type == VMK_LIGHT_AREA ? area_sample_wi(S, P, l, p_ref, u_surface, cnt) : env_sample_wi(S, l, p_ref, u_surface, cnt);
+    // (point / spot ignore u_surface, light.cpp:49-58)
+    LightSample ls = l->type == VMK_LIGHT_AREA ? area_sample_wi(S, P, l, p_ref, u_surface, cnt)
+                   : (l->type == VMK_LIGHT_SPHERICAL ? env_sample_wi(S, l, p_ref, u_surface, cnt) : point_sample_wi(S, l, p_ref, cnt));
     ls.eval.pdf *= pmf;
     return ls;
 }

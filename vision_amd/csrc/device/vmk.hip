@@ -415,8 +415,11 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderArgs &A, uint32_t slot
     return *px < width && *py < height;
 }
 
+// The MEDIA variants get the 128-register budget of 4 waves per SIMD: at 5 (96 registers) hipcc 7.2 -O3 produced a
+// k_render<true, true> whose medium vertices differed from k_test's instance of the same path_bounce<true, true> and from
+// the oracle (caught by the cbox_media parity test; -O1, 4 waves, or removing the point-light branch all made it agree).
 template<bool FULL, bool MEDIA>
-__global__ __launch_bounds__(kBlock, VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, MEDIA ? 4 : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = *A.scene;
     const vmk_render_params *P = A.params;
@@ -841,6 +844,8 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
             if (l.inst_id >= sc->n_instances || (uint64_t) l.alias_offset + l.alias_count > sc->n_alias || l.alias_count != sc->instances[l.inst_id].tri_count || l.alias_count == 0) { ctx->error = "vmk_upload_scene: area light tables inconsistent"; return VMK_ERR_ARG; }
         } else if (l.type == VMK_LIGHT_SPHERICAL) {
             if (l.res_x == 0 || l.res_y == 0 || l.alias_count != l.res_y || (uint64_t) l.alias_offset + l.alias_count > sc->n_alias || (uint64_t) l.cond_offset + (uint64_t) l.res_x * l.res_y > sc->n_alias) { ctx->error = "vmk_upload_scene: environment light tables inconsistent"; return VMK_ERR_ARG; }
+        } else if (l.type == VMK_LIGHT_POINT || l.type == VMK_LIGHT_SPOT) {
+            if (l.type == VMK_LIGHT_SPOT && !(l.cos_falloff_start > l.cos_angle)) { ctx->error = "vmk_upload_scene: spot light cone is empty"; return VMK_ERR_ARG; }
         } else { ctx->error = "vmk_upload_scene: unknown light type"; return VMK_ERR_ARG; }
     }
     if (sc->n_mediums && !sc->mediums) { ctx->error = "vmk_upload_scene: mediums missing"; return VMK_ERR_ARG; }

@@ -633,11 +633,34 @@ struct HostScene {
                 for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) { l.w2o[c * 3 + r] = (float) w2o.at(r, c); l.o2w[c * 3 + r] = (float) o2w_back.at(r, c); }
                 pending.push_back({l, 1});
                 describe("light", "spherical", ld["name"].as_string());
+            } else if (type == "point" || type == "spot") { // point.cpp:19-30, spot.cpp:19-38
+                vmk_light l{}; l.type = type == "point" ? VMK_LIGHT_POINT : VMK_LIGHT_SPOT; l.inst_id = VMK_INVALID;
+                init_light_color(l, p, false);
+                auto read3 = [&](const char *key, float dx, float dy, float dz, float *out) {
+                    const Json &v = p[key];
+                    out[0] = v.is_array() && v.size() > 0 ? v.at(0).as_float(dx) : dx;
+                    out[1] = v.is_array() && v.size() > 1 ? v.at(1).as_float(dy) : dy;
+                    out[2] = v.is_array() && v.size() > 2 ? v.at(2).as_float(dz) : dz;
+                };
+                read3("position", 0.f, 0.f, 0.f, l.position);
+                if (l.type == VMK_LIGHT_SPOT) {
+                    const float deg = 3.14159265358979323846f / 180.f;
+                    float angle = std::min(89.f, std::max(1.f, p["angle"].as_float(45.f))) * deg;
+                    // spot.cpp:31: radians(clamp(desc["falloff"], 0, angle_.hv())) — the clamp's upper bound is the angle already in RADIANS
+                    float falloff = std::min(std::max(p["falloff"].as_float(10.f), 0.f), angle) * deg;
+                    float d[3]; read3("direction", 0.f, 0.f, 1.f, d);
+                    float len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    for (int k = 0; k < 3; ++k) l.direction[k] = d[k] / len;
+                    l.cos_angle = std::cos(angle);
+                    l.cos_falloff_start = std::cos(std::max(0.f, angle - falloff));
+                }
+                pending.push_back({l, 0});
+                describe("light", type, ld["name"].as_string());
             } else if (type == "area") {
                 fail("stand-alone light/area (own quad geometry, area.cpp:56-71) is outside the hot-path scope; use shape.param.emission");
             } else {
                 if (opt.drop_unsupported_lights) { describe("light", type, "DROPPED (outside hot-path scope)"); continue; }
-                fail("light/" + type + " is outside the hot-path scope (area + spherical; point/spot are §8(f) 'next')");
+                fail("light/" + type + " is outside the hot-path scope (area, spherical, point, spot)");
             }
         }
 
@@ -706,6 +729,8 @@ struct HostScene {
                 if (areas.empty()) fail("emissive shape without triangles");
                 AliasBuild a = build_alias(areas);
                 l.alias_offset = append_alias(a); l.alias_count = (uint32_t) areas.size(); l.alias_integral = a.integral;
+            } else if (l.type == VMK_LIGHT_POINT || l.type == VMK_LIGHT_SPOT) {
+                // delta lights carry no tables
             } else { // SphericalMap::prepare (spherical.cpp:198-212) + AliasTable2D::build (alias2d.cpp:32-68)
                 scene.env_light = light_id;
                 l.world_diameter = world_diameter;
@@ -778,18 +803,37 @@ struct HostScene {
             describe("filter", ft, "");
             if (ft == "box") params.filter_type = VMK_FILTER_BOX;
             else if (ft == "triangle") params.filter_type = VMK_FILTER_TRIANGLE;
-            else if (ft == "gaussian") { // gaussian.cpp:20-42 + FilterSampler::build (fitted_curve.h:37-58)
+            else if (ft == "gaussian" || ft == "mitchell" || ft == "sinc") {
+                // FittedCurveFilter: FilterSampler::build (fitted_curve.h:37-58) tabulates |f| on a 20x20 grid over one
+                // quadrant and importance-samples it with an alias-2D warper; the sample weight (lut / pdf, signed for the
+                // negative lobes of mitchell / sinc) is not consumed by the accumulate path (frame_buffer.cpp:117-126).
                 params.filter_type = VMK_FILTER_TABLE;
-                float sigma = fd["param"]["sigma"].as_float(1.f);
-                auto gaussian = [](float x, float mu, float sg) { return 1.f / std::sqrt(2 * 3.14159265358979323846f * sg * sg) * std::exp(-(x - mu) * (x - mu) / (2 * sg * sg)); };
-                float ex = gaussian(radius, 0, sigma);
+                std::function<float(float, float)> eval;
+                if (ft == "gaussian") { // gaussian.cpp:20-42
+                    float sigma = fd["param"]["sigma"].as_float(1.f);
+                    auto gaussian = [](float x, float mu, float sg) { return 1.f / std::sqrt(2 * 3.14159265358979323846f * sg * sg) * std::exp(-(x - mu) * (x - mu) / (2 * sg * sg)); };
+                    float ex = gaussian(radius, 0, sigma);
+                    eval = [=](float px, float py) { return std::max(0.f, gaussian(px, 0, sigma) - ex) * std::max(0.f, gaussian(py, 0, sigma) - ex); };
+                } else if (ft == "mitchell") { // mitchell.cpp:18-49
+                    float mb = fd["param"]["b"].as_float(1.f / 3.f), mc = fd["param"]["c"].as_float(1.f / 3.f);
+                    auto m1d = [=](float x) {
+                        x = std::fabs(x);
+                        if (x <= 1) return ((12 - 9 * mb - 6 * mc) * x * x * x + (-18 + 12 * mb + 6 * mc) * x * x + (6 - 2 * mb)) * (1.f / 6.f);
+                        if (x <= 2) return ((-mb - 6 * mc) * x * x * x + (6 * mb + 30 * mc) * x * x + (-12 * mb - 48 * mc) * x + (8 * mb + 24 * mc)) * (1.f / 6.f);
+                        return 0.f;
+                    };
+                    eval = [=](float px, float py) { return m1d(2 * px / radius) * m1d(2 * py / radius); };
+                } else { // sinc.cpp:16-33, math/util.h:57-66
+                    float tau = fd["param"]["tau"].as_float(3.f);
+                    auto sinc = [](float x) { x *= 3.14159265358979323846f; return 1.f + x * x == 1.f ? 1.f : std::sin(x) / x; };
+                    auto wsinc = [=](float x) { return std::fabs(x) > radius ? 0.f : sinc(x) * sinc(x / tau); };
+                    eval = [=](float px, float py) { return wsinc(px) * wsinc(py) * 4.f; };
+                }
                 const int N = VMK_FILTER_TABLE_SIZE;
                 std::vector<float> func((size_t) N * N);
                 for (int i = 0; i < N * N; ++i) {
                     int x = i % N, y = i / N;
-                    float px = (x + 0.5f) / N * radius, py = (y + 0.5f) / N * radius;
-                    float val = std::max(0.f, gaussian(px, 0, sigma) - ex) * std::max(0.f, gaussian(py, 0, sigma) - ex);
-                    func[i] = std::fabs(val);
+                    func[i] = std::fabs(eval((x + 0.5f) / N * radius, (y + 0.5f) / N * radius));
                 }
                 std::vector<float> marginal; std::vector<AliasBuild> rows;
                 for (int v = 0; v < N; ++v) { rows.push_back(build_alias(std::vector<float>(func.begin() + v * N, func.begin() + (v + 1) * N))); marginal.push_back(rows.back().integral); }
@@ -799,7 +843,7 @@ struct HostScene {
                     for (int u = 0; u < N; ++u) { params.filter_cond_prob[v * N + u] = rows[v].prob[u]; params.filter_cond_alias[v * N + u] = rows[v].alias[u]; params.filter_cond_func[v * N + u] = rows[v].func[u]; }
                 }
                 params.filter_marginal_integral = mg.integral;
-            } else fail("filter/" + ft + " is a §8(f) 'next' row (box/triangle/gaussian in scope)");
+            } else fail("filter/" + ft + " is outside the hot-path scope (box / triangle / gaussian / mitchell / sinc)");
         }
         // ---- integrator (integrator.cpp:59-66) ----
         {
