@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-replay", action="store_true", help="skip the traversal-only replay of the megakernel's own rays")
     ap.add_argument("--save", default=None, help="write the final tone-mapped picture (rank 0)")
     a = ap.parse_args()
 
@@ -148,6 +149,27 @@ def main():
                          "traffic": None, "kernel": "k_render", "avg_kernel_ms": avg_ms,
                          "traversal_GBs": b_trav / a.steps / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0},
         }
+        # measured device-to-device copy bandwidth of this GPU in the same run (quote the fraction against both)
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)  # 1 GiB each
+        dst.copy_(src); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize(dev)
+        copy_gbs = 8 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # read + write
+        del src, dst
+        out["roofline"]["measured_copy_GBs"] = copy_gbs
+        out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+        # traversal-only replay: the rays the megakernel traces (captured by k_test kind 7, bit-identical to the
+        # oracle's) replayed through k_trace; algorithmic bytes = 128 B per node visit + 48 B per triangle test + 44 B per ray
+        if world == 1 and not a.no_replay:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from gpu_replay import replay
+            rp = replay(pipe)
+            out["roofline"]["traversal_replay"] = {k: {"mrays_s": rp[k]["mrays_s"], "achieved_GBs": rp[k]["algorithmic_GBs"], "frac": rp[k]["frac_of_8TBs"],
+                                                       "nodes_per_ray": rp[k]["nodes_per_ray"], "tris_per_ray": rp[k]["tris_per_ray"]}
+                                                   for k in ("closest", "shadow") if k in rp}
         # HBM traffic of k_render from separate rocprofv3 --pmc passes of this same command (tools/summarize_profiles.py);
         # only attached when the profiled workload matches this run, otherwise null.
         pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")

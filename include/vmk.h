@@ -301,6 +301,14 @@ int vmk_accel_info_get(vmk_ctx *ctx, vmk_accel_info *out);
 int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *dir_xyz, const float *tmax,
                    int any_hit, uint32_t *hit_out /* n*4 */, float *kernel_ms, uint32_t repeats);
 
+/* ---- AOV pass (FrameBuffer::compile_compute_geom, src/base/sensor/frame_buffer.cpp:156-219) -----------------
+ * Primary-hit planes of frame `frame` for denoisers / image tooling: shading normal (w = 1 on a hit, 0 on a
+ * miss), MaterialEvaluator::albedo (material.cpp:91-98), emitted radiance (evaluate_hit_wi), each width*height
+ * RGBA floats, and linear depth = (world-to-camera * p).z (sensor.cpp:192-195), width*height floats.  Any output
+ * may be NULL.  Motion vectors are not produced (static camera per render). */
+int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba,
+                   float *depth);
+
 /* ---- albedo-table precompute (the reference's vision-precompute app, src/apps/precompute/main.cpp:24-41;
  * Material::precompute_lobe base/scattering/material.h:121-163; Lobe::integral_albedo lobe.cpp:13-33) --------
  * Integrates table `which` (0 PureReflection res^2, 1 Dielectric / 2 DielectricInv res^3 x 2 floats {total,

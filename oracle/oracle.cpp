@@ -583,6 +583,8 @@ struct Lobe {
     bool compensate{false}; // PureReflectionLobe::compensate (mirror / conductor / metallic)
     uint32_t bxdf_flags{flag::DiffRefl};
     float weight{1.f}, sample_weight{1.f};
+    int albedo_lut{0};      // 0: class default, 1: CoatLobe::albedo (principled_bsdf.cpp:154-160), 2: SpecularLobe::albedo (:198-205)
+    float lut_x{0}, lut_z{0};
 };
 struct LobeSet { int n{0}; bool is_set{false}; Lobe lobes[12]; };
 struct MatCtx { const vmk_scene *s; };
@@ -939,6 +941,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
         float sv; sample_lut3d(s->luts.coat, 1, make_float3(x, cos_t, z), &sv);
         float3 albedo = l.kr * sv;
         l.sample_weight = average(albedo); l.weight = 1.f;
+        l.albedo_lut = 1; l.lut_x = x; l.lut_z = z;
         weight = layering_weight(albedo, weight);
         push(l);
     }
@@ -972,6 +975,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
         float sv; sample_lut3d(s->luts.specular, 1, make_float3(x, cos_t, z), &sv);
         float3 albedo = lerp3(sv, l.fr.a, make_float3(1.f)) * l.kr;
         l.sample_weight = average(albedo); l.weight = 1.f;
+        l.albedo_lut = 2; l.lut_x = x; l.lut_z = z;
         push(l);
         weight = layering_weight(albedo, weight);
     }
@@ -1229,6 +1233,49 @@ inline Ray generate_ray(const vmk_render_params &p, uint32_t px, uint32_t py, Sa
 }
 
 // =====================================================================================================
+// §8f-3. AOVs of the primary hit — FrameBuffer::compile_compute_geom (frame_buffer.cpp:156-219): shading normal,
+//        linear depth (sensor.cpp:192-195), MaterialEvaluator::albedo (material.cpp:91-98) = LobeSet::albedo
+//        (lobe.cpp:564-570) over the per-class Lobe::albedo, emission via evaluate_hit_wi
+// =====================================================================================================
+inline float3 lobe_albedo(const vmk_scene *s, const Lobe &l, float cos_theta) {
+    switch (l.kind) {
+        case LB_LAMBERT: case LB_OREN_NAYAR: case LB_FRESNEL_BLEND: return l.kr; // bxdf.h:91,153; substrate.cpp:22
+        case LB_MICROFACET: {
+            if (l.albedo_lut == 1) { float sv; sample_lut3d(s->luts.coat, 1, make_float3(l.lut_x, cos_theta, l.lut_z), &sv); return sv * l.kr; }
+            if (l.albedo_lut == 2) { float sv; sample_lut3d(s->luts.specular, 1, make_float3(l.lut_x, cos_theta, l.lut_z), &sv); return lerp3(sv, l.fr.a, make_float3(1.f)) * l.kr; }
+            return l.kr * l.fr.evaluate(cos_theta); // MicrofacetLobe::albedo lobe.cpp:208-210
+        }
+        case LB_DIELECTRIC: { float3 F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; } // lobe.cpp:308-313
+        default: return l.kr; // sheen: its directional albedo is folded into kr at build time (principled_bsdf.cpp:54-57)
+    }
+}
+struct PixelAov { float3 normal, albedo, emission; float depth; bool hit; };
+inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const float *w2c, uint32_t px, uint32_t py, uint32_t frame) {
+    PixelAov a{make_float3(0.f), make_float3(0.f), make_float3(0.f), 0.f, false};
+    const vmk_scene *s = sv.s;
+    Sampler sampler; sampler.start(px, py, frame, 0);
+    Ray ray = generate_ray(p, px, py, sampler);
+    Hit hit = sv.trace_closest(ray);
+    if (hit.is_miss()) return a;
+    a.hit = true;
+    Interaction it = compute_surface_interaction(s, hit, ray);
+    a.normal = it.shading.z;
+    a.depth = w2c[2] * it.pos.x + w2c[6] * it.pos.y + w2c[10] * it.pos.z + w2c[14]; // transform_point(w2c, pos).z, column-major
+    if (it.has_material()) {
+        LobeSet lobes; build_lobe_set(s, s->materials[it.mat_id], it, lobes);
+        float cos_theta = dot(it.shading.z, it.wo);
+        if (!lobes.is_set) a.albedo = lobe_albedo(s, lobes.lobes[0], cos_theta);
+        else for (int i = 0; i < lobes.n; ++i) a.albedo += lobe_albedo(s, lobes.lobes[i], cos_theta) * lobes.lobes[i].weight;
+    }
+    if (it.has_emission()) {
+        LightCtx lc{s, &p};
+        LightSampleContext p_ref{ray.o, ray.d};
+        a.emission = light_evaluate_hit_wi(lc, p_ref, it).L;
+    }
+    return a;
+}
+
+// =====================================================================================================
 // §8f-1. Homogeneous medium + Henyey-Greenstein phase function — render_core/medium/homogeneous.cpp:30-70,
 //        base/scattering/interaction.h:136-139, interaction.cpp:12-32,114-134, geometry.cpp:187-199
 // =====================================================================================================
@@ -1481,6 +1528,23 @@ uint32_t orc_dump_rays(void *h, const vmk_render_params *p, uint32_t frame, uint
     uint32_t n = (uint32_t) (dump.words.size() / 10);
     if (out) { n = std::min(n, max_rays); std::memcpy(out, dump.words.data(), (size_t) n * 40); }
     return n;
+}
+
+// AOV planes of frame `frame` (frame_buffer.cpp:156-219): any output may be null.  normal/albedo/emission are RGBA (w = 1 like
+// the reference's buffers), depth one float per pixel; misses leave zeros.
+int orc_render_aov(void *h, const vmk_render_params *p, const float *w2c, uint32_t frame, float *normal, float *albedo, float *emission, float *depth) {
+    SceneView &sv = ((orc_scene_handle *) h)->sv;
+    for (uint32_t y = 0; y < p->height; ++y)
+        for (uint32_t x = 0; x < p->width; ++x) {
+            PixelAov a = primary_aov(sv, *p, w2c, x, y, frame);
+            size_t i = (size_t) y * p->width + x;
+            if (normal) { normal[4 * i] = a.normal.x; normal[4 * i + 1] = a.normal.y; normal[4 * i + 2] = a.normal.z; normal[4 * i + 3] = a.hit ? 1.f : 0.f; }
+            if (albedo) { albedo[4 * i] = a.albedo.x; albedo[4 * i + 1] = a.albedo.y; albedo[4 * i + 2] = a.albedo.z; albedo[4 * i + 3] = 1.f; }
+            if (emission) { emission[4 * i] = a.emission.x; emission[4 * i + 1] = a.emission.y; emission[4 * i + 2] = a.emission.z; emission[4 * i + 3] = 1.f; }
+            if (depth) depth[i] = a.depth;
+        }
+    sv.flush_thread_counters();
+    return 0;
 }
 
 void orc_reset_counters(void *h) {

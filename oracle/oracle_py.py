@@ -42,6 +42,7 @@ def lib():
         L.orc_test_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                     C.c_void_p, C.c_uint32]
         L.orc_integrate_albedo.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+        L.orc_render_aov.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_dump_rays.restype = C.c_uint32
         L.orc_dump_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         _LIB = L
@@ -77,6 +78,16 @@ class OracleScene:
         tmax = np.ascontiguousarray(tmax, np.float32)
         out = np.zeros((n, 4), np.uint32)
         lib().orc_trace_rays(self._h, n, _ptr(org), _ptr(dirs), _ptr(tmax), int(any_hit), _ptr(out))
+        return out
+
+    def render_aov(self, params, frame=0):
+        """CPU restatement of the reference's G-buffer kernel (frame_buffer.cpp:156-219): normal / albedo / emission / depth."""
+        h, w = params.height, params.width
+        c2w = np.array(params.c2w, np.float64).reshape(4, 4).T  # column-major storage
+        w2c = np.ascontiguousarray(np.linalg.inv(c2w).T.astype(np.float32)).reshape(-1)  # back to column-major floats
+        out = {k: np.zeros((h, w, 4), np.float32) for k in ("normal", "albedo", "emission")}
+        out["depth"] = np.zeros((h, w), np.float32)
+        lib().orc_render_aov(self._h, C.byref(params), _ptr(w2c), frame, _ptr(out["normal"]), _ptr(out["albedo"]), _ptr(out["emission"]), _ptr(out["depth"]))
         return out
 
     def dump_rays(self, params, frame=0, stride=1):

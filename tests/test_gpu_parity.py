@@ -228,3 +228,17 @@ def test_hip_albedo_precompute_matches_oracle_and_reference_tables(backend, whic
     if which != 0:
         tol[0] *= 2.0  # z = 0 is the index-matched end (ior 1.003): heavy-tailed weights, the reference's own 2^21-sample texels scatter by +-0.02 there
     assert (err <= tol).all(), (names[which], float((err / tol).max()))
+
+
+@pytest.mark.parametrize("scene, w, h, kw", [("scenes/cbox/cbox_materials.json", 64, 64, {}), ("scenes/classroom/vision_scene.json", 96, 54, {}),
+                                            ("scenes/cbox/cbox_lights.json", 40, 40, {})])
+def test_aov_planes_match_oracle(backend, scene, w, h, kw):
+    """vmk_render_aov (the reference's G-buffer kernel, frame_buffer.cpp:156-219): shading normal, linear depth, material
+    albedo (every lobe class incl. the LUT-based coat / specular albedos of principled_bsdf) and emission, bit for bit."""
+    hs, p, osc, _ = _load(backend, scene, w, h, **kw)
+    g = backend.render_aov(frame=2)
+    o = osc.render_aov(p, frame=2)
+    for k in ("normal", "albedo", "emission"):
+        assert _bits_equal(g[k], o[k]), k
+    assert np.allclose(g["depth"], o["depth"], rtol=2e-6, atol=1e-6)  # the two sides invert the camera matrix independently
+    assert (g["normal"][..., 3] == 1.0).mean() > 0.5

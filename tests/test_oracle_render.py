@@ -91,3 +91,19 @@ def test_two_rank_allreduce_reassembles_the_image(built, tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DIST_OK" in out.stdout
+
+
+def test_oracle_aov_planes_are_consistent(built):
+    """The G-buffer restatement (frame_buffer.cpp:156-219): unit shading normals on hits, positive linear depth, the
+    emitter plane is non-zero exactly on the light, and a Lambert surface's albedo is its colour slot."""
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_matte.json"), width=48, height=48)
+    a = oracle_py.OracleScene(hs).render_aov(hs.params_copy(), frame=0)
+    hit = a["normal"][..., 3] == 1.0
+    assert hit.mean() > 0.9
+    assert np.allclose(np.linalg.norm(a["normal"][hit][:, :3], axis=1), 1.0, atol=1e-5)
+    assert (a["depth"][hit] > 0).all() and (a["depth"][~hit] == 0).all()
+    lit = a["emission"][..., :3].sum(-1) > 0
+    assert 0 < lit.sum() < hit.sum() * 0.2
+    # every material of cbox_matte is diffuse: albedo in [0, 1], and the distinct albedo values are the scene's colours
+    alb = a["albedo"][hit][:, :3]
+    assert alb.min() >= 0.0 and alb.max() <= 1.0 and len(np.unique(alb.round(5), axis=0)) <= hs.scene.n_materials + 1

@@ -769,6 +769,36 @@ VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i
         default: l.kind = LB_LAMBERT; l.kr = mc.kr_diff; break;
     }
 }
+// MaterialEvaluator::albedo (material.cpp:91-98) = LobeSet::albedo (lobe.cpp:564-570) over the per-class Lobe::albedo
+// (bxdf.h:91,153; substrate.cpp:22; lobe.cpp:208-210,308-313; CoatLobe / SpecularLobe principled_bsdf.cpp:154-160,198-205);
+// used by the AOV pass only (frame_buffer.cpp:192-196), always instantiated with FULL = true.
+VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, const Lobe &l, float cos_theta) {
+    switch (l.kind) {
+        case LB_MICROFACET: {
+            if (mc.is_set && mc.m->type == VMK_MAT_PRINCIPLED && (k == 1 || k == 4)) {
+                float x = sqrt_(sqrt_(l.ax * l.ay));
+                if (k == 1) { float sv; sample_lut3d<1>(S.lut_coat, mk3(x, cos_theta, inverse_lerp(mc.cc_ior, 1.003f, 4.f)), &sv); return sv * l.kr; }
+                float z = sqrt_(abs_((mc.ior - 1.0f) / (mc.ior + 1.0f)));
+                float sv; sample_lut3d<1>(S.lut_specular, mk3(x, cos_theta, z), &sv);
+                return lerp3(sv, l.fr.a, mk3(1.f)) * l.kr;
+            }
+            return l.kr * l.fr.evaluate(cos_theta);
+        }
+        case LB_DIELECTRIC: { V3 F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; }
+        default: return l.kr; // Lambert / Oren-Nayar / FresnelBlend Rd / sheen (albedo folded into kr at build time)
+    }
+}
+VD V3 mat_albedo(const DScene &S, const MatCtx &mc, const Interaction &it, DCounters &cnt) {
+    float cos_theta = dot(it.shading.z, it.wo);
+    Lobe l;
+    if (!mc.is_set) { mat_lobe<true>(S, mc, it, 0, l, cnt); return lobe_albedo(S, mc, 0, l, cos_theta); }
+    V3 sum = mk3(0.f);
+    for (int i = 0; i < mc.n; ++i) {
+        mat_lobe<true>(S, mc, it, i, l, cnt);
+        sum += lobe_albedo(S, mc, i + (mc.m->type == VMK_MAT_PRINCIPLED ? mc.first : 0), l, cos_theta) * l.weight;
+    }
+    return sum;
+}
 // Lobe::evaluate / LobeSet::evaluate_impl (lobe.cpp:53-75,673-688) in world space; all lobes share it.shading.
 // A single-lobe material is the n = 1 case of the same loop (its weights are 1, so the products are exact).
 template<bool FULL>

@@ -646,6 +646,57 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// AOV pass (FrameBuffer::compile_compute_geom, frame_buffer.cpp:156-219): the primary hit's shading normal, linear depth
+// (sensor.cpp:192-195), material albedo and emitted radiance for frame `frame` — what a denoiser is handed.  One lane per
+// pixel; the primary rays go through the same wave-cooperative traversal as the megakernel's.
+// ---------------------------------------------------------------------------------------------------------
+struct AovArgs {
+    const DScene *scene;
+    const vmk_render_params *params;
+    float4 *normal, *albedo, *emission; // RGBA planes or null
+    float *depth;
+    uint32_t frame;
+    float w2c_z[4]; // third row of world-to-camera
+};
+__global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
+    __shared__ WaveScratch s_ws[kBlock / 64];
+    const DScene S = *A.scene;
+    const vmk_render_params *P = A.params;
+    WaveScratch *ws = s_ws + (threadIdx.x >> 6);
+    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+    const uint32_t n = P->width * P->height;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) { // block-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t px = live ? i % P->width : 0u, py = live ? i / P->width : 0u;
+        Sampler sampler; sampler.start(px, py, A.frame, 0);
+        Ray ray = generate_ray(P, px, py, sampler);
+        Hit hit;
+        bool found = traverse_wave(S, ray, live, false, ws, hit, cnt);
+        if (!live) continue;
+        V3 normal = mk3(0.f), albedo = mk3(0.f), emission = mk3(0.f);
+        float depth = 0.f;
+        if (found) {
+            Interaction it;
+            compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
+            it.wo = normalize(-ray.d);
+            normal = it.shading.z;
+            depth = A.w2c_z[0] * it.pos.x + A.w2c_z[1] * it.pos.y + A.w2c_z[2] * it.pos.z + A.w2c_z[3];
+            if (it.mat_id != VMK_INVALID) {
+                MatCtx mc;
+                mat_prepare<true>(S, S.materials + it.mat_id, it, mc, cnt);
+                albedo = mat_albedo(S, mc, it, cnt);
+            }
+            if (it.light_id != VMK_INVALID) emission = light_evaluate_hit_wi(S, P, ray.o, it, cnt).L;
+        }
+        if (A.normal) A.normal[i] = make_float4(normal.x, normal.y, normal.z, found ? 1.f : 0.f);
+        if (A.albedo) A.albedo[i] = make_float4(albedo.x, albedo.y, albedo.z, 1.f);
+        if (A.emission) A.emission[i] = make_float4(emission.x, emission.y, emission.z, 1.f);
+        if (A.depth) A.depth[i] = depth;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Albedo-table precompute (the reference's `vision-precompute` app, apps/precompute/main.cpp:24-41):
 // Material::precompute_lobe (material.h:121-163) — texel (x, y, z) of a res^3 (res^2 for table 0) grid, ratio =
 // idx / (res - 1), sampler.start((x, y), 0, 0), Lobe::precompute_with_radio + integral_albedo (lobe.cpp:13-33) in
@@ -1197,6 +1248,51 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     if (kernel_ms) *kernel_ms = ms / (float) repeats;
     cleanup();
     if (e != hipSuccess) { ctx->error = std::string("vmk_trace_rays: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    return VMK_OK;
+}
+
+int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba, float *depth) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!ctx->accel_ready || !ctx->params_ready) { ctx->error = "vmk_render_aov: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t) ctx->params.width * ctx->params.height;
+    DevBuf<float4> dn, da, de; DevBuf<float> dd;
+    auto cleanup = [&]() { dn.release(); da.release(); de.release(); dd.release(); };
+    hipError_t e = hipSuccess;
+    if (normal_rgba) e = dn.alloc(n);
+    if (e == hipSuccess && albedo_rgba) e = da.alloc(n);
+    if (e == hipSuccess && emission_rgba) e = de.alloc(n);
+    if (e == hipSuccess && depth) e = dd.alloc(n);
+    if (e != hipSuccess) { cleanup(); ctx->error = std::string("vmk_render_aov: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    AovArgs A{};
+    A.scene = ctx->d_scene.p; A.params = ctx->d_params.p; A.normal = dn.p; A.albedo = da.p; A.emission = de.p; A.depth = dd.p; A.frame = frame;
+    { // third row of inverse(c2w), column-major 4x4, in double (Sensor::linear_depth sensor.cpp:192-195)
+        const float *m = ctx->params.c2w;
+        double a[16], inv[16];
+        for (int i = 0; i < 16; ++i) a[i] = m[i];
+        // cofactors of the third row of the inverse = third column of the adjugate
+        inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+        inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+        inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+        inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+        inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+        inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+        inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+        inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+        double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+        if (det == 0.0) { cleanup(); ctx->error = "vmk_render_aov: camera matrix is singular"; return VMK_ERR_ARG; }
+        A.w2c_z[0] = (float) (inv[2] / det); A.w2c_z[1] = (float) (inv[6] / det); A.w2c_z[2] = (float) (inv[10] / det); A.w2c_z[3] = (float) (inv[14] / det);
+    }
+    uint32_t grid = (uint32_t) std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * 6);
+    hipLaunchKernelGGL(k_aov, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
+    e = hipGetLastError();
+    if (e == hipSuccess && normal_rgba) e = hipMemcpyAsync(normal_rgba, dn.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && albedo_rgba) e = hipMemcpyAsync(albedo_rgba, da.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && emission_rgba) e = hipMemcpyAsync(emission_rgba, de.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && depth) e = hipMemcpyAsync(depth, dd.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) { ctx->error = std::string("vmk_render_aov: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
     return VMK_OK;
 }
 

@@ -118,6 +118,11 @@ class Pipeline:
     def compile(self):
         self.integrator.compile()
 
+    def render_aov(self, frame=0):
+        """G-buffer planes of the primary hit (FrameBuffer::compute_GBuffer, frame_buffer.cpp:156-219,322-339): normal,
+        albedo, emission [H, W, 4] and linear depth [H, W] — the denoiser hand-off of the reference."""
+        return self.backend.render_aov(frame)
+
     def change_resolution(self, width, height):
         """Pipeline::change_resolution: re-derives the camera matrices for the new film size (sensor.cpp:58-71)."""
         path = self.host_scene.json_path
