@@ -101,6 +101,7 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("classroom_fog", "scenes/classroom/vision_scene.json", 48, 27, 2),  # the scene as shipped: global fog
     ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4),         # point + spot lights, mitchell filter (§8f-2)
     ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),             # point light, Lanczos-sinc filter
+    ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),  # config 4 (srgb): glass + metal, depth 32
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog"))
@@ -116,6 +117,20 @@ def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     for k in ("closest_rays", "shadow_rays", "paths", "surface_hits"):
         assert cg[k] == co[k], (k, cg[k], co[k])
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "not bit-exact (within tolerance, but the build is designed to be exact)"
+
+
+def test_glass_of_water_depth_64_parity(backend):
+    """BASELINE config 4's integrator setting (max depth 64, min depth 3) on the glass-of-water scene in srgb mode."""
+    hs, p, osc, _ = _load(backend, "scenes/glass-of-water/vision_scene.json", 96, 96, max_depth=64, min_depth=3)
+    assert p.max_depth == 64
+    backend.reset_accum(); backend.reset_counters()
+    backend.render_batch(0, 2)
+    img = backend.download_accum()
+    ref, co = osc.render(p, 0, 2)
+    cg = backend.counters()
+    assert rel_l2(img, ref) <= TOL_REL_L2
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert cg["closest_rays"] == co["closest_rays"] and cg["shadow_rays"] == co["shadow_rays"]
 
 
 def test_larger_render_parity_classroom(backend):

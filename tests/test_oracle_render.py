@@ -17,7 +17,9 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          # participating media honoured (vmk_host_options.mediums = 1): global fog + a material-less smoke volume; classroom's own fog
          ("cbox_media", "scenes/cbox/cbox_media.json", 32, 32, 4), ("classroom_fog", "scenes/classroom/vision_scene.json", 48, 27, 2),
          # point + spot lights, mitchell / Lanczos-sinc pixel filters (SURVEY 8f rank 2 without the spectral part)
-         ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4), ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4)]
+         ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4), ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),
+         # BASELINE config 4 in srgb mode: rough / smooth dielectrics + conductors, max depth 32 (divergence stress)
+         ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2)]
 MEDIA = {"cbox_media", "classroom_fog"}
 
 
