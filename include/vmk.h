@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VMK_ABI_VERSION 2u
+#define VMK_ABI_VERSION 3u
 #define VMK_INVALID 0xFFFFFFFFu
 
 typedef enum vmk_status {
@@ -195,6 +195,10 @@ typedef struct vmk_scene {
     vmk_luts luts;
     uint32_t n_mediums;
     const vmk_medium *mediums; /* MediumRegistry order (scene.cpp:189-199) */
+    /* lightsampler/power (render_core/lightsampler/power.cpp:35-52): alias table over luminance(light->power()), one
+     * entry per light in lights[] order (the environment light weighs 0 when env_separate); VMK_INVALID when absent */
+    uint32_t light_alias_offset;
+    float light_alias_integral;
 } vmk_scene;
 
 /* ---- camera / film / integrator ---------------------------------------------------------------------- */
@@ -233,6 +237,7 @@ typedef struct vmk_render_params {
      * (photosensory.cpp:11-32, sensor.cpp:48) */
     uint32_t process_mediums;
     uint32_t camera_medium; /* index into mediums[] or VMK_INVALID */
+    uint32_t light_sampler; /* 0 "uniform" (uniform.cpp), 1 "power" (power.cpp; needs vmk_scene::light_alias_offset) */
 } vmk_render_params;
 
 /* Tile ownership for multi-GPU sharding: image cut into tile_size^2 tiles in row-major order, tile t is

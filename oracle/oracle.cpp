@@ -1038,32 +1038,46 @@ inline float alias_PDF(const vmk_scene *s, const vmk_light &l, uint32_t i) { // 
 }
 struct LightCtx { const vmk_scene *s; const vmk_render_params *p; };
 
-inline float light_select_PMF(const LightCtx &c, uint32_t index) { // lightsampler.cpp:159-176, uniform.cpp:13-20
+// LightSampler::PMF / select_light (lightsampler.cpp:159-197) over the sampler's own PMF_ / select_light_:
+// uniform (uniform.cpp:13-34, punctual lights only + correct_index when the environment is sampled separately) or
+// power (power.cpp:13-28: alias table over luminance(power()), all lights, the environment weighing 0 when separate)
+inline float light_pmf_inner(const LightCtx &c, uint32_t index) {
     uint32_t n = c.s->n_lights;
-    bool has_env = c.s->env_light != VMK_INVALID;
-    if (c.p->env_separate && has_env) {
-        float env_prob = c.p->env_prob;
-        uint32_t punctual = n - 1u;
-        if (index == c.s->env_light) return env_prob;
-        return (1.f - env_prob) * (1.f / (float) punctual);
-    }
-    return 1.f / (float) n;
+    if (c.p->light_sampler == 1)
+        return c.s->light_alias_integral > 0.f ? c.s->alias_func[c.s->light_alias_offset + index] / (c.s->light_alias_integral * (float) n) : 0.f;
+    bool sep = c.p->env_separate && c.s->env_light != VMK_INVALID;
+    return 1.f / (float) (sep ? n - 1u : n);
 }
-inline void light_select(const LightCtx &c, float u, uint32_t *index, float *pmf) { // lightsampler.cpp:178-197, uniform.cpp:23-34
+inline uint32_t light_select_inner(const LightCtx &c, float u) {
     uint32_t n = c.s->n_lights;
-    bool has_env = c.s->env_light != VMK_INVALID;
-    if (c.p->env_separate && has_env) {
+    if (c.p->light_sampler == 1) { uint32_t idx; float ur; alias_offset_u_remapped(c.s, c.s->light_alias_offset, n, u, &idx, &ur); return idx; }
+    bool sep = c.p->env_separate && c.s->env_light != VMK_INVALID;
+    if (sep) {
+        uint32_t punctual = n - 1u;
+        uint32_t idx = (uint32_t) fmin_(u * (float) punctual, (float) punctual - 1.f);
+        return idx < c.s->env_light ? idx : idx + 1u; // correct_index lightsampler.cpp:33-38
+    }
+    return (uint32_t) fmin_(u * (float) n, (float) n - 1.f);
+}
+inline float light_select_PMF(const LightCtx &c, uint32_t index) {
+    if (c.p->env_separate && c.s->env_light != VMK_INVALID) {
+        float env_prob = c.p->env_prob;
+        if (index == c.s->env_light) return env_prob;
+        return (1.f - env_prob) * light_pmf_inner(c, index);
+    }
+    return light_pmf_inner(c, index);
+}
+inline void light_select(const LightCtx &c, float u, uint32_t *index, float *pmf) {
+    if (c.p->env_separate && c.s->env_light != VMK_INVALID) {
         float env_prob = c.p->env_prob;
         if (u < env_prob) { *index = c.s->env_light; *pmf = env_prob; return; }
         u = remapping(u, env_prob, 1.f);
-        uint32_t punctual = n - 1u;
-        uint32_t idx = (uint32_t) fmin_(u * (float) punctual, (float) punctual - 1.f);
-        idx = idx < c.s->env_light ? idx : idx + 1u; // correct_index lightsampler.cpp:33-38
-        *index = idx; *pmf = (1.f / (float) punctual) * (1.f - env_prob);
+        *index = light_select_inner(c, u);
+        *pmf = light_pmf_inner(c, *index) * (1.f - env_prob);
         return;
     }
-    *index = (uint32_t) fmin_(u * (float) n, (float) n - 1.f);
-    *pmf = 1.f / (float) n;
+    *index = light_select_inner(c, u);
+    *pmf = light_pmf_inner(c, *index);
 }
 inline float3 area_L(const vmk_scene *s, const vmk_light &l, float2 uv, float3 ng, float3 w) { // area.cpp:91-95
     float3 radiance = eval_slot3(s, l.color, uv) * l.scale;

@@ -102,6 +102,7 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4),         # point + spot lights, mitchell filter (§8f-2)
     ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),             # point light, Lanczos-sinc filter
     ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),  # config 4 (srgb): glass + metal, depth 32
+    ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4),           # lightsampler/power
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog"))
@@ -117,6 +118,21 @@ def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     for k in ("closest_rays", "shadow_rays", "paths", "surface_hits"):
         assert cg[k] == co[k], (k, cg[k], co[k])
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "not bit-exact (within tolerance, but the build is designed to be exact)"
+
+
+def test_config1_cbox_1024x1024_matches_oracle_on_sampled_tiles(backend):
+    """BASELINE.json configs[1] at its full resolution (cbox 1024x1024, matte-only): the GPU renders the whole image, the
+    oracle every 64th 32x32 tile of it (tile ownership shards exactly), and those 16k pixels agree bit for bit."""
+    from vision_amd import _abi
+    hs, p, osc, _ = _load(backend, "scenes/cbox/cbox_matte.json", 1024, 1024)
+    backend.reset_accum()
+    backend.render_batch(0, 8)
+    img = backend.download_accum()
+    ref, cc = osc.render(p, 0, 8, tiles=_abi.Tiles(32, 5, 64))
+    owned = ref[..., 3] != 0.0
+    assert owned.sum() == 16 * 32 * 32 and cc["paths"] == owned.sum() * 8
+    assert np.array_equal(img[owned].view(np.uint32), ref[owned].view(np.uint32))
+    assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
 
 
 def test_glass_of_water_depth_64_parity(backend):

@@ -152,3 +152,24 @@ def test_point_spot_lights_and_fitted_filters(built):
     c = np.array(hs2.params.filter_cond_func, np.float32).reshape(20, 20)
     # windowed sinc with radius 1.5 crosses zero at |x| = 1: the tabulated |f| dips there (column 13 ~ x = 1.0125)
     assert c[0, 13] < c[0, 10] and c[0, 13] < c[0, 16]
+
+
+def test_power_light_sampler_table(built):
+    """lightsampler/power (power.cpp:35-52): alias table over luminance(power()) in light order."""
+    import math
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_power.json"), width=16, height=16)
+    sc = hs.scene
+    assert hs.params.light_sampler == 1 and sc.light_alias_offset != _abi.INVALID
+    func = [sc.alias_func[sc.light_alias_offset + i] for i in range(sc.n_lights)]
+    for i, f in enumerate(func):
+        l = sc.lights[i]
+        avg = [l.color.v[k] * l.scale for k in range(3)]
+        lum = 0.212671 * avg[0] + 0.715160 * avg[1] + 0.072169 * avg[2]
+        if l.type == 2:
+            assert f == pytest.approx(4 * math.pi * lum, rel=1e-5)                      # point.cpp:33-35
+        elif l.type == 0:
+            area = sum(sc.alias_func[l.alias_offset + k] for k in range(l.alias_count))
+            assert f == pytest.approx((2 if l.two_sided else 1) * area * math.pi * lum, rel=1e-5)  # area.cpp:87-89
+    assert sc.light_alias_integral == pytest.approx(sum(func) / len(func), rel=1e-6)
+    uni = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_lights.json"), width=16, height=16)
+    assert uni.params.light_sampler == 0 and uni.scene.light_alias_offset == _abi.INVALID

@@ -19,7 +19,8 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          # point + spot lights, mitchell / Lanczos-sinc pixel filters (SURVEY 8f rank 2 without the spectral part)
          ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4), ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),
          # BASELINE config 4 in srgb mode: rough / smooth dielectrics + conductors, max depth 32 (divergence stress)
-         ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2)]
+         ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
+         ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4)]  # lightsampler/power over area + point + spot
 MEDIA = {"cbox_media", "classroom_fog"}
 
 
@@ -109,3 +110,14 @@ def test_oracle_aov_planes_are_consistent(built):
     # every material of cbox_matte is diffuse: albedo in [0, 1], and the distinct albedo values are the scene's colours
     alb = a["albedo"][hit][:, :3]
     assert alb.min() >= 0.0 and alb.max() <= 1.0 and len(np.unique(alb.round(5), axis=0)) <= hs.scene.n_materials + 1
+
+
+def test_config0_cbox_256x256_16spp_on_cpu(built):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): cbox 256x256 at 16 spp on the CPU restatement.
+    The result is deterministic down to the bit (own elementary functions, no contraction), so it is pinned by a digest."""
+    import hashlib
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_matte.json"), width=256, height=256)
+    img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, 16)
+    assert cnt["paths"] == 256 * 256 * 16 and (cnt["closest_rays"], cnt["shadow_rays"]) == (3266952, 2837842)
+    assert np.isfinite(img).all() and abs(float(img[..., :3].mean()) - 0.12030963) < 1e-6
+    assert hashlib.sha1(img.tobytes()).hexdigest() == "d1091f91e538ad218d058984b94095a981f874da"

@@ -1,7 +1,7 @@
 """ctypes mirror of include/vmk.h and include/vmk_host.h (plain C structs, no torch types)."""
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 INVALID = 0xFFFFFFFF
 MAX_SLOTS = 18
 LUT_RES = 32
@@ -60,7 +60,8 @@ class Scene(C.Structure):
                 ("tex_data", C.POINTER(C.c_uint8)), ("tex_bytes", u64),
                 ("alias_prob", C.POINTER(f32)), ("alias_idx", C.POINTER(u32)), ("alias_func", C.POINTER(f32)),
                 ("env_light", u32), ("world_min", f32 * 3), ("world_max", f32 * 3), ("luts", Luts),
-                ("n_mediums", u32), ("mediums", C.POINTER(Medium))]
+                ("n_mediums", u32), ("mediums", C.POINTER(Medium)),
+                ("light_alias_offset", u32), ("light_alias_integral", f32)]
 
 
 _T = FILTER_TABLE_SIZE
@@ -75,7 +76,7 @@ class RenderParams(C.Structure):
                 ("filter_cond_func", f32 * (_T * _T)),
                 ("max_depth", u32), ("min_depth", u32), ("rr_threshold", f32), ("mis_mode", u32),
                 ("env_separate", u32), ("env_prob", f32), ("ray_offset_factor", f32), ("exposure", f32),
-                ("tone_mapper", u32), ("process_mediums", u32), ("camera_medium", u32)]
+                ("tone_mapper", u32), ("process_mediums", u32), ("camera_medium", u32), ("light_sampler", u32)]
 
 
 class Tiles(C.Structure):

@@ -890,30 +890,46 @@ VD float alias_PMF(const DScene &S, const vmk_light *l, uint32_t i) { // alias.h
 VD float alias_PDF(const DScene &S, const vmk_light *l, uint32_t i) { // alias.h:44-46
     return l->alias_integral > 0.f ? S.alias_func[l->alias_offset + i] / l->alias_integral : 0.f;
 }
-VD float light_select_PMF(const DScene &S, const vmk_render_params *P, uint32_t index) { // lightsampler.cpp:159-176, uniform.cpp:13-20
+// LightSampler::PMF / select_light (lightsampler.cpp:159-197) over the sampler's own PMF_ / select_light_:
+// uniform (uniform.cpp:13-34, punctual lights only + correct_index when the environment is sampled separately) or
+// power (power.cpp:13-28: alias table over luminance(power()), all lights, the environment weighing 0 when separate)
+VD float light_pmf_inner(const DScene &S, const vmk_render_params *P, uint32_t index) {
     uint32_t n = S.n_lights;
+    if (P->light_sampler == 1)
+        return S.light_alias_integral > 0.f ? S.alias_func[S.light_alias_offset + index] / (S.light_alias_integral * (float) n) : 0.f;
+    bool sep = P->env_separate && S.env_light != VMK_INVALID;
+    return 1.f / (float) (sep ? n - 1u : n);
+}
+VD uint32_t light_select_inner(const DScene &S, const vmk_render_params *P, float u) {
+    uint32_t n = S.n_lights;
+    if (P->light_sampler == 1) { uint32_t idx; float ur; alias_offset_u_remapped(S, S.light_alias_offset, n, u, &idx, &ur); return idx; }
+    bool sep = P->env_separate && S.env_light != VMK_INVALID;
+    if (sep) {
+        uint32_t punctual = n - 1u;
+        uint32_t idx = (uint32_t) fmin_(u * (float) punctual, (float) punctual - 1.f);
+        return idx < S.env_light ? idx : idx + 1u; // correct_index lightsampler.cpp:33-38
+    }
+    return (uint32_t) fmin_(u * (float) n, (float) n - 1.f);
+}
+VD float light_select_PMF(const DScene &S, const vmk_render_params *P, uint32_t index) {
     if (P->env_separate && S.env_light != VMK_INVALID) {
         float env_prob = P->env_prob;
-        uint32_t punctual = n - 1u;
         if (index == S.env_light) return env_prob;
-        return (1.f - env_prob) * (1.f / (float) punctual);
+        return (1.f - env_prob) * light_pmf_inner(S, P, index);
     }
-    return 1.f / (float) n;
+    return light_pmf_inner(S, P, index);
 }
-VD void light_select(const DScene &S, const vmk_render_params *P, float u, uint32_t *index, float *pmf) { // lightsampler.cpp:178-197, uniform.cpp:23-34
-    uint32_t n = S.n_lights;
+VD void light_select(const DScene &S, const vmk_render_params *P, float u, uint32_t *index, float *pmf) {
     if (P->env_separate && S.env_light != VMK_INVALID) {
         float env_prob = P->env_prob;
         if (u < env_prob) { *index = S.env_light; *pmf = env_prob; return; }
         u = remapping(u, env_prob, 1.f);
-        uint32_t punctual = n - 1u;
-        uint32_t idx = (uint32_t) fmin_(u * (float) punctual, (float) punctual - 1.f);
-        idx = idx < S.env_light ? idx : idx + 1u;
-        *index = idx; *pmf = (1.f / (float) punctual) * (1.f - env_prob);
+        *index = light_select_inner(S, P, u);
+        *pmf = light_pmf_inner(S, P, *index) * (1.f - env_prob);
         return;
     }
-    *index = (uint32_t) fmin_(u * (float) n, (float) n - 1.f);
-    *pmf = 1.f / (float) n;
+    *index = light_select_inner(S, P, u);
+    *pmf = light_pmf_inner(S, P, *index);
 }
 VD V3 area_L(const DScene &S, const vmk_light *l, V2 uv, V3 ng, V3 w, DCounters &cnt) { // area.cpp:91-95
     V3 radiance = eval_slot3(S, l->color, uv, cnt) * l->scale;

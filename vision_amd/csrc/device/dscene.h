@@ -41,6 +41,8 @@ struct DScene {
     const BvhNode *nodes;
     int32_t root; // reference of the root: node 0, or leaf-encoded when the scene has <= kMaxLeafTris triangles
     uint32_t n_tris, n_lights, env_light;
+    uint32_t light_alias_offset; // lightsampler/power table (VMK_INVALID when absent)
+    float light_alias_integral;
 };
 
 struct DCounters { // per-lane tallies, wave-reduced into vmk_counters at kernel end

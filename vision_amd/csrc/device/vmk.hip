@@ -792,6 +792,7 @@ struct vmk_ctx {
     DevBuf<vmk_light> lights;
     DevBuf<vmk_medium> mediums;
     uint32_t n_mediums{0};
+    bool has_light_alias{false};
     DevBuf<vmk_texture> textures;
     DevBuf<uint8_t> tex_data;
     DevBuf<float> alias_prob, alias_func, srgb_lut, luts;
@@ -899,6 +900,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
             if (l.type == VMK_LIGHT_SPOT && !(l.cos_falloff_start > l.cos_angle)) { ctx->error = "vmk_upload_scene: spot light cone is empty"; return VMK_ERR_ARG; }
         } else { ctx->error = "vmk_upload_scene: unknown light type"; return VMK_ERR_ARG; }
     }
+    if (sc->light_alias_offset != VMK_INVALID && (uint64_t) sc->light_alias_offset + sc->n_lights > sc->n_alias) { ctx->error = "vmk_upload_scene: light-sampler alias table out of range"; return VMK_ERR_ARG; }
     if (sc->n_mediums && !sc->mediums) { ctx->error = "vmk_upload_scene: mediums missing"; return VMK_ERR_ARG; }
     for (uint32_t i = 0; i < sc->n_instances; ++i) {
         const vmk_instance &in = sc->instances[i];
@@ -940,6 +942,8 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     h.lut_pure_reflection = ctx->luts.p + off[0]; h.lut_dielectric = ctx->luts.p + off[1]; h.lut_dielectric_inv = ctx->luts.p + off[2];
     h.lut_specular = ctx->luts.p + off[3]; h.lut_coat = ctx->luts.p + off[4]; h.lut_sheen_approx = src[5] ? ctx->luts.p + off[5] : nullptr;
     h.n_tris = sc->n_tris; h.n_lights = sc->n_lights; h.env_light = sc->env_light;
+    h.light_alias_offset = sc->light_alias_offset; h.light_alias_integral = sc->light_alias_integral;
+    ctx->has_light_alias = sc->light_alias_offset != VMK_INVALID;
     for (int k = 0; k < 3; ++k) { ctx->world_min[k] = sc->world_min[k]; ctx->world_max[k] = sc->world_max[k]; }
     HIP_TRY(hipStreamSynchronize(st));
     ctx->scene_ready = true; ctx->accel_ready = false;
@@ -1078,7 +1082,7 @@ int vmk_accel_info_get(vmk_ctx *ctx, vmk_accel_info *out) {
 int vmk_set_render_params(vmk_ctx *ctx, const vmk_render_params *p) {
     if (!ctx) return VMK_ERR_ARG;
     if (!p || p->width == 0 || p->height == 0 || (uint64_t) p->width * p->height > (1ull << 30)) { ctx->error = "vmk_set_render_params: bad resolution"; return VMK_ERR_ARG; }
-    if (p->filter_type > VMK_FILTER_TABLE || p->mis_mode > 2) { ctx->error = "vmk_set_render_params: bad filter / mis mode"; return VMK_ERR_ARG; }
+    if (p->filter_type > VMK_FILTER_TABLE || p->mis_mode > 2 || p->light_sampler > 1) { ctx->error = "vmk_set_render_params: bad filter / mis mode / light sampler"; return VMK_ERR_ARG; }
     if (p->filter_type == VMK_FILTER_TABLE) {
         for (uint32_t i = 0; i < VMK_FILTER_TABLE_SIZE; ++i) if (p->filter_marginal_alias[i] >= VMK_FILTER_TABLE_SIZE) { ctx->error = "vmk_set_render_params: filter alias out of range"; return VMK_ERR_ARG; }
         for (uint32_t i = 0; i < VMK_FILTER_TABLE_SIZE * VMK_FILTER_TABLE_SIZE; ++i) if (p->filter_cond_alias[i] >= VMK_FILTER_TABLE_SIZE) { ctx->error = "vmk_set_render_params: filter alias out of range"; return VMK_ERR_ARG; }
@@ -1119,6 +1123,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready || !ctx->fb) { ctx->error = "vmk_render_batch: scene/accel/params not ready"; return VMK_ERR_STATE; }
     if (ctx->params.process_mediums && ctx->params.camera_medium != VMK_INVALID && ctx->params.camera_medium >= ctx->n_mediums) { ctx->error = "vmk_render_batch: camera medium out of range"; return VMK_ERR_ARG; }
+    if (ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_render_batch: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     if (kernel_ms) *kernel_ms = 0.f;
     if (frame_count == 0) return VMK_OK;
     RenderArgs A{};
@@ -1254,6 +1259,7 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
 int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba, float *depth) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready) { ctx->error = "vmk_render_aov: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    if (ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_render_aov: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t) ctx->params.width * ctx->params.height;
     DevBuf<float4> dn, da, de; DevBuf<float> dd;
@@ -1321,6 +1327,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     if (in_stride < min_in[kind] || out_stride < min_out[kind]) { ctx->error = "vmk_test_eval: stride too small for this kind"; return VMK_ERR_ARG; }
     if (kind == 4 && !ctx->accel_ready) { ctx->error = "vmk_test_eval: kind 4 needs an uploaded scene + accel"; return VMK_ERR_STATE; }
     if ((kind == 6 || kind == 7) && (!ctx->accel_ready || !ctx->params_ready)) { ctx->error = "vmk_test_eval: kinds 6/7 need scene, accel and render params"; return VMK_ERR_STATE; }
+    if ((kind == 6 || kind == 7) && ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_test_eval: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     if ((kind == 6 || kind == 7) && ctx->params.process_mediums && ctx->params.camera_medium != VMK_INVALID && ctx->params.camera_medium >= ctx->n_mediums) { ctx->error = "vmk_test_eval: camera medium out of range"; return VMK_ERR_ARG; }
     if (kind == 5 && !ctx->params_ready) { ctx->error = "vmk_test_eval: kind 5 needs render params"; return VMK_ERR_STATE; }
     if (kind == 4) { // material ids are validated here: the kernel indexes materials[] with them

@@ -613,8 +613,9 @@ struct HostScene {
         // ---- light_sampler descs first (lights listed in JSON precede shape emissions: LightSampler ctor lightsampler.cpp:15-27) ----
         const Json &lsd = root["light_sampler"];
         std::string ls_type = lsd["type"].as_string("uniform");
-        if (ls_type != "uniform") fail("lightsampler/" + ls_type + " is outside the hot-path scope (uniform only)");
-        describe("lightsampler", "uniform", "");
+        if (ls_type != "uniform" && ls_type != "power") fail("lightsampler/" + ls_type + " is outside the hot-path scope (uniform, power)");
+        describe("lightsampler", ls_type, "");
+        params.light_sampler = ls_type == "power" ? 1u : 0u;
         params.env_separate = lsd["param"]["env_separate"].as_bool(false) ? 1u : 0u;
         params.env_prob = std::min(0.99f, std::max(0.01f, lsd["param"]["env_prob"].as_float(0.5f)));
         struct PendingLight { vmk_light l; int order; };
@@ -759,7 +760,41 @@ struct HostScene {
             }
             lights.push_back(l);
         }
-        if (lights.empty() && !list_only) fail("scene has no light inside the hot-path scope (area / spherical)");
+        if (lights.empty() && !list_only) fail("scene has no light inside the hot-path scope (area / spherical / point / spot)");
+        // ---- PowerLightSampler::prepare (power.cpp:35-52): alias table over luminance(power()) ----
+        scene.light_alias_offset = VMK_INVALID; scene.light_alias_integral = 0.f;
+        if (params.light_sampler == 1 && !list_only) {
+            std::vector<float> weights;
+            for (const vmk_light &l : lights) {
+                // Light::average() = colour average * scale (light.h:80-83); an image colour averages its texels
+                float avg[3] = {l.color.v[0], l.color.v[1], l.color.v[2]};
+                if (l.color.tex != VMK_INVALID) {
+                    const vmk_texture &t = textures[l.color.tex & 0xffffu];
+                    double acc[3] = {0, 0, 0};
+                    for (size_t i = 0; i < (size_t) t.width * t.height; ++i) {
+                        if (t.format == VMK_TEX_RGBA32F) { const float *px = (const float *) (tex_data.data() + t.offset) + i * 4; for (int k = 0; k < 3; ++k) acc[k] += px[k]; }
+                        else { const uint8_t *px = tex_data.data() + t.offset + i * 4; for (int k = 0; k < 3; ++k) acc[k] += px[k] / 255.0; }
+                    }
+                    for (int k = 0; k < 3; ++k) avg[k] = (float) (acc[k] / ((double) t.width * t.height)) * l.color.v[0];
+                }
+                for (float &c : avg) c *= l.scale;
+                float f = 0.f;
+                const float pi = 3.14159265358979323846f;
+                if (l.type == VMK_LIGHT_AREA) { // area.cpp:87-89
+                    float area = alias_func_sum(l);
+                    f = (l.two_sided ? 2.f : 1.f) * area * pi;
+                } else if (l.type == VMK_LIGHT_SPHERICAL) { // spherical.cpp:56-59; weighs nothing when sampled separately
+                    f = params.env_separate ? 0.f : pi * (l.world_diameter / 2.f) * (l.world_diameter / 2.f);
+                } else if (l.type == VMK_LIGHT_POINT) f = 4.f * pi; // point.cpp:33-35
+                else { // spot.cpp:48-50 (angles in radians)
+                    float angle = std::acos(l.cos_angle), start = std::acos(l.cos_falloff_start);
+                    f = 2.f * pi * (1.f - .5f * (angle * 2.f + (angle - start)));
+                }
+                weights.push_back(0.212671f * avg[0] * f + 0.715160f * avg[1] * f + 0.072169f * avg[2] * f); // luminance(power())
+            }
+            AliasBuild a = build_alias(weights);
+            scene.light_alias_offset = append_alias(a); scene.light_alias_integral = a.integral;
+        }
 
         // ---- sensor (sensor.cpp:17-25,58-78,153-162; thin_lens.cpp:16-20) ----
         const Json &cam = root["camera"];
@@ -894,6 +929,11 @@ struct HostScene {
         for (int i = 0; i < 5; ++i) if (!*dst[i]) fail("albedo-table blob lacks a required table");
     }
 
+    float alias_func_sum(const vmk_light &l) const { // an area light's table holds its triangle areas: surface_area()
+        float sum = 0.f;
+        for (uint32_t i = 0; i < l.alias_count; ++i) sum += alias_func[l.alias_offset + i];
+        return sum;
+    }
     uint32_t medium_id(const std::string &name) const {
         for (uint32_t i = 0; i < medium_names.size(); ++i) if (medium_names[i] == name) return i;
         return VMK_INVALID;
