@@ -12,7 +12,11 @@ os.makedirs(out, exist_ok=True)
 def short(n):
     return n.split("(")[0][-60:]
 
-stats = list(csv.DictReader(open(glob.glob(os.path.join(prof, "kt", "*", "*_kernel_stats.csv"))[0])))
+def newest(pattern):  # gpurun merges every call's files into the same local directory: take the latest run
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+stats = list(csv.DictReader(open(newest(os.path.join(prof, "kt", "*", "*_kernel_stats.csv"))[0])))
 with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
     for r in stats[:12]:
@@ -20,7 +24,7 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
 kr = max((r for r in stats if "k_render" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 
 def pmc(name):
-    f = glob.glob(os.path.join(prof, name, "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(prof, name, "*", "*_counter_collection.csv"))
     if not f:
         return {}, {}
     rows = [r for r in csv.DictReader(open(f[0])) if "k_render" in r["Kernel_Name"]]
