@@ -69,9 +69,13 @@ def test_product_fails_loudly_without_gpu(built):
 
 
 def test_product_never_imports_the_oracle():
-    """The oracle is test infrastructure: nothing under vision_amd/ may reference it."""
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "vision_amd")):
-        for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp", ".inl")):
-                text = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "oracle_py" not in text and "oracle/" not in text and "liboracle" not in text, os.path.join(dirpath, f)
+    """The oracle is test infrastructure: nothing under vision_amd/ or tools/ may import, load or link it (only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg do)."""
+    for top in ("vision_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".inl", ".sh")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle_py" not in text and "import oracle" not in text and "liboracle" not in text, os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("oracle_py") == 2 and "cpu_baseline" in bench.split("from oracle import oracle_py")[1][:1200]
