@@ -345,3 +345,32 @@ def test_large_scene_build_and_trace(backend, tmp_path):
     hg, _ = backend.trace(org, d, tmax)
     assert np.array_equal(hg, osc.trace(org, d, tmax))
     assert (hg[:, 0] != 0xFFFFFFFF).mean() > 0.5
+
+
+@pytest.mark.parametrize("w, h, max_depth, min_depth, tiles", [
+    (33, 17, 0, 0, None),            # `$for(&bounces, 0, max_depth)` never runs: black film, no rays
+    (33, 17, 1, 5, None),            # one bounce, min_depth beyond max_depth
+    (1, 1, 4, 0, None),              # a single pixel
+    (37, 29, 3, 0, (8, 2, 3)),       # odd size, small tiles, rank 2 of 3
+    (37, 29, 3, 0, (64, 5, 7)),      # one tile covers the image: rank 5 owns nothing
+    (70, 40, 16, 5, (64, 1, 2)),     # partially covered tiles at the image border
+])
+def test_render_edge_cases(backend, w, h, max_depth, min_depth, tiles):
+    """Film / work-distribution edge cases against the oracle: zero depth, single pixel, sizes that are not tile multiples,
+    ranks that own few or no tiles."""
+    from vision_amd import _abi
+    hs, p, osc, _ = _load(backend, "scenes/cbox/cbox_materials.json", w, h, max_depth=max_depth, min_depth=min_depth)
+    t = _abi.Tiles(*tiles) if tiles else None
+    backend.reset_accum(); backend.reset_counters()
+    backend.render_batch(0, 3, tiles=t)
+    backend.render_batch(3, 2, tiles=t)
+    img = backend.download_accum()
+    cg = backend.counters()
+    ref, co = osc.render(p, 0, 5, tiles=t)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    for k in ("closest_rays", "shadow_rays", "paths", "surface_hits"):
+        assert cg[k] == co[k], (k, cg[k], co[k])
+    if max_depth == 0:
+        assert cg["closest_rays"] == 0 and (img[..., :3] == 0).all()
+    if tiles == (64, 5, 7):
+        assert cg["paths"] == 0 and (img == 0).all()
