@@ -27,7 +27,16 @@ def main():
     t0 = time.time()
     tabs = backend.precompute_albedo_tables(a.samples, N)
     print(f"integrated 5 tables in {time.time() - t0:.1f} s; means", [float(t.mean()) for t in tabs])
-    counts = [len(t) for t in tabs] + [0, 0]  # sheen LTC tables absent
+    sheen = []  # tables 5/6 (sheen LTC coefficients, tools/make_sheen_tables.py) are carried over from the existing blob
+    default_blob = os.path.join(ROOT, "vision_amd", "data", "luts.bin")
+    if os.path.exists(default_blob):
+        raw = open(default_blob, "rb").read()
+        _, _, *old = struct.unpack("<II7I", raw[:36])
+        off = 36 + 4 * sum(old[:5])
+        for c in old[5:]:
+            sheen.append(np.frombuffer(raw[off:off + 4 * c], np.float32)); off += 4 * c
+    tabs = list(tabs) + sheen
+    counts = [len(t) for t in tabs] + [0] * (7 - len(tabs))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "wb") as f:
         f.write(struct.pack("<II7I", 0x54554C56, 1, *counts))
