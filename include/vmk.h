@@ -63,8 +63,12 @@ typedef enum vmk_material_type {
     VMK_MAT_GLASS = 3,      /* "glass"            glass.cpp:240-257   slots: color, ior, roughness, anisotropic */
     VMK_MAT_SUBSTRATE = 4,  /* "substrate"        substrate.cpp:126-149 slots: color, spec, roughness, anisotropic */
     VMK_MAT_PRINCIPLED = 5, /* "principled_bsdf"  principled_bsdf.cpp:352-461, 18 slots in declaration order */
-    VMK_MAT_MIX = 6         /* "mix"              mix.cpp:66-71       slot: frac; children child0/child1 */
+    VMK_MAT_MIX = 6,        /* "mix"              mix.cpp:66-71       slot: frac; children child0/child1 */
+    VMK_MAT_METALLIC = 7,   /* "metallic"         metallic.cpp:24-60  slots: color, edge_tint, roughness, anisotropic (F82-tint conductor) */
+    VMK_MAT_ADD = 8         /* "add"              add.cpp:9-60        children child0/child1, LobeSet::create_add (lobe.cpp:510-522) */
 } vmk_material_type;
+/* single-lobe types may be children of mix / add */
+#define VMK_MAT_IS_SINGLE_LOBE(t) ((t) <= VMK_MAT_SUBSTRATE || (t) == VMK_MAT_METALLIC)
 
 enum { /* principled slot indices, principled_bsdf.cpp:235-256 */
     VMK_P_COLOR = 0, VMK_P_METALLIC, VMK_P_IOR, VMK_P_ROUGHNESS, VMK_P_SPEC_TINT, VMK_P_ANISOTROPIC, VMK_P_OPACITY,
@@ -89,7 +93,7 @@ typedef struct vmk_slot {
 typedef struct vmk_material {
     uint32_t type;  /* vmk_material_type */
     uint32_t flags; /* VMK_MATF_* */
-    uint32_t child0, child1; /* mix only: indices into materials[] (must be non-mix) */
+    uint32_t child0, child1; /* mix / add only: indices into materials[] (single-lobe types) */
     vmk_slot slot[VMK_MAX_SLOTS];
 } vmk_material;
 

@@ -877,6 +877,13 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
             l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
             break;
         }
+        case VMK_MAT_METALLIC: { // metallic.cpp:42-60: MetallicLobe = PureReflectionLobe with compensation, F82-tint Fresnel
+            l.kind = LB_MICROFACET; l.kr = eval_slot3(s, m.slot[0], it.uv);
+            microfacet_alpha(s, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay);
+            l.fr.kind = FR_F82; l.fr.a = l.kr; f82_init(l.fr, eval_slot3(s, m.slot[1], it.uv));
+            l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
+            break;
+        }
         case VMK_MAT_GLASS: { // glass.cpp:240-257
             l.kind = LB_DIELECTRIC; l.kr = eval_slot3(s, m.slot[0], it.uv);
             float ior = eval_slot1(s, m.slot[1], it.uv);
@@ -992,18 +999,20 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
 }
 inline void build_lobe_set(const vmk_scene *s, const vmk_material &m, const Interaction &it, LobeSet &out) {
     if (m.type == VMK_MAT_PRINCIPLED) { build_principled(s, m, it, out); return; }
-    if (m.type == VMK_MAT_MIX) { // mix.cpp:66-71, LobeSet::create_mix + flatten (lobe.cpp:495-508,534-562)
-        float frac = eval_slot1(s, m.slot[0], it.uv);
-        float w[2] = {1.f - frac, frac};
+    if (m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD) { // mix.cpp:66-71 / add.cpp:57-60; LobeSet::create_mix / create_add + flatten (lobe.cpp:495-522,534-562)
+        float frac = m.type == VMK_MAT_MIX ? eval_slot1(s, m.slot[0], it.uv) : 0.f;
+        float w[2] = {1.f - frac, frac};          // lobe weights
+        float sw[2] = {1.f - frac, frac};         // sampling weights
+        if (m.type == VMK_MAT_ADD) { w[0] = w[1] = 1.f; sw[0] = sw[1] = 1.f / (1.f + 1.f); } // {1, 1} then normalize_sampled_weight
         out.is_set = true; out.n = 0;
         for (int c = 0; c < 2; ++c) {
             const vmk_material &cm = s->materials[c == 0 ? m.child0 : m.child1];
             if (cm.type == VMK_MAT_PRINCIPLED) {
                 LobeSet sub; build_principled(s, cm, it, sub);
-                for (int i = 0; i < sub.n; ++i) { Lobe l = sub.lobes[i]; l.sample_weight *= w[c]; l.weight *= w[c]; out.lobes[out.n++] = l; }
+                for (int i = 0; i < sub.n; ++i) { Lobe l = sub.lobes[i]; l.sample_weight *= sw[c]; l.weight *= w[c]; out.lobes[out.n++] = l; }
             } else {
                 Lobe l; build_simple_lobe(s, cm, it, l);
-                l.sample_weight = w[c]; l.weight = w[c];
+                l.sample_weight = sw[c]; l.weight = w[c];
                 out.lobes[out.n++] = l;
             }
         }

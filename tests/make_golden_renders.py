@@ -16,7 +16,7 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          ("cbox_media", "scenes/cbox/cbox_media.json", 32, 32, 4), ("classroom_fog", "scenes/classroom/vision_scene.json", 48, 27, 2),
          ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4), ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),
          ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
-         ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4), ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4)]
+         ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4), ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4), ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4)]
 MEDIA = {"cbox_media", "classroom_fog"}  # rendered with the scene's "mediums" block honoured
 for name, path, w, h, spp in CASES:
     hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA)

@@ -52,7 +52,7 @@ def test_device_units_rng_math_warps_microfacet(backend):
     assert _bits_equal(backend.test_eval(3, a, 8), oracle_py.test_eval_noscene(3, a, 8))
 
 
-@pytest.mark.parametrize("scene", ["scenes/cbox/cbox_matte.json", "scenes/cbox/cbox_materials.json", "scenes/cbox/cbox_media.json", "scenes/cbox/cbox_sheen.json"])
+@pytest.mark.parametrize("scene", ["scenes/cbox/cbox_matte.json", "scenes/cbox/cbox_materials.json", "scenes/cbox/cbox_media.json", "scenes/cbox/cbox_sheen.json", "scenes/cbox/cbox_extra.json"])
 def test_material_camera_and_path_units(backend, scene):
     """Every material type: evaluate + sample on random (wo, wi, uv, rng stream); camera rays; whole-path records."""
     hs, p, osc, _ = _load(backend, scene, 48, 48, mediums=scene.endswith("cbox_media.json"))
@@ -104,6 +104,7 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),  # config 4 (srgb): glass + metal, depth 32
     ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4),           # lightsampler/power
     ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4),           # principled_bsdf sheen (LTC) layer
+    ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4),           # material/metallic, material/add
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog"))
@@ -262,7 +263,7 @@ def test_hip_albedo_precompute_matches_oracle_and_reference_tables(backend, whic
     assert (err <= tol).all(), (names[which], float((err / tol).max()))
 
 
-@pytest.mark.parametrize("scene, w, h, kw", [("scenes/cbox/cbox_materials.json", 64, 64, {}), ("scenes/classroom/vision_scene.json", 96, 54, {}), ("scenes/cbox/cbox_sheen.json", 48, 48, {}),
+@pytest.mark.parametrize("scene, w, h, kw", [("scenes/cbox/cbox_materials.json", 64, 64, {}), ("scenes/classroom/vision_scene.json", 96, 54, {}), ("scenes/cbox/cbox_sheen.json", 48, 48, {}), ("scenes/cbox/cbox_extra.json", 48, 48, {}),
                                             ("scenes/cbox/cbox_lights.json", 40, 40, {})])
 def test_aov_planes_match_oracle(backend, scene, w, h, kw):
     """vmk_render_aov (the reference's G-buffer kernel, frame_buffer.cpp:156-219): shading normal, linear depth, material

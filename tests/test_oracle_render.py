@@ -21,7 +21,8 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          # BASELINE config 4 in srgb mode: rough / smooth dielectrics + conductors, max depth 32 (divergence stress)
          ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
          ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4),  # lightsampler/power over area + point + spot
-         ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4)]  # principled_bsdf with its sheen (LTC) layer
+         ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4),  # principled_bsdf with its sheen (LTC) layer
+         ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4)]  # material/metallic and material/add
 MEDIA = {"cbox_media", "classroom_fog"}
 
 

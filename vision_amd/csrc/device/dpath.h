@@ -600,6 +600,17 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
             l.compensate = true;
             break;
         }
+        case VMK_MAT_METALLIC: { // metallic.cpp:42-60: MetallicLobe = PureReflectionLobe with compensation, F82-tint Fresnel
+            l.kind = LB_MICROFACET; l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            microfacet_alpha(S, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay, cnt);
+            V3 edge_tint = eval_slot3(S, m->slot[1], it.uv, cnt);
+            const float f = 6.f / 7.f;
+            const float f5 = pow5(f);
+            V3 f_schlick = lerp3(f5, l.kr, mk3(1.f)); // FresnelF82Tint::init_from_F82 fresnel.h:115-121
+            l.fr.kind = FR_F82; l.fr.a = l.kr; l.fr.b = f_schlick * (7.f / (f5 * f)) * (mk3(1.f) - edge_tint);
+            l.compensate = true;
+            break;
+        }
         case VMK_MAT_GLASS: { // glass.cpp:240-257, interaction.cpp:80-83
             l.kind = LB_DIELECTRIC; l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
             float ior = eval_slot1(S, m->slot[1], it.uv, cnt);
@@ -634,7 +645,7 @@ struct MatCtx {
     int n;        // lobes
     bool is_set;  // LobeSet semantics (weights, valid_world_factor, 3 burnt draws)
     Lobe single;  // simple materials: the lobe itself
-    float mixw[2];
+    float mixw[2], mixsw[2]; // mix / add: lobe weights and sampling weights of the two children
     // principled
     int first;    // 0 with sheen, 1 without
     V3 color, spec_tint, kr_sheen, kr_coat, kr_metal, kr_spec, kr_diff;
@@ -656,6 +667,13 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
     if (m->type == VMK_MAT_MIX) { // mix.cpp:66-71 + LobeSet::create_mix (lobe.cpp:495-508)
         float frac = eval_slot1(S, m->slot[0], it.uv, cnt);
         mc.mixw[0] = 1.f - frac; mc.mixw[1] = frac;
+        mc.mixsw[0] = 1.f - frac; mc.mixsw[1] = frac;
+        mc.n = 2; mc.is_set = true;
+        return;
+    }
+    if (m->type == VMK_MAT_ADD) { // add.cpp:57-60 + LobeSet::create_add (lobe.cpp:510-522): weights {1, 1}, sampling weights normalised
+        mc.mixw[0] = 1.f; mc.mixw[1] = 1.f;
+        mc.mixsw[0] = 1.f / (1.f + 1.f); mc.mixsw[1] = 1.f / (1.f + 1.f);
         mc.n = 2; mc.is_set = true;
         return;
     }
@@ -751,9 +769,9 @@ template<bool FULL>
 VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i, Lobe &l, DCounters &cnt) {
     if constexpr (!FULL) { l = mc.single; return; }
     const vmk_material *m = mc.m;
-    if (m->type == VMK_MAT_MIX) {
+    if (m->type == VMK_MAT_MIX || m->type == VMK_MAT_ADD) {
         build_simple_lobe(S, S.materials + (i == 0 ? m->child0 : m->child1), it, l, cnt);
-        { float mw = i == 0 ? mc.mixw[0] : mc.mixw[1]; l.weight = mw; l.sample_weight = mw; }
+        l.weight = i == 0 ? mc.mixw[0] : mc.mixw[1]; l.sample_weight = i == 0 ? mc.mixsw[0] : mc.mixsw[1];
         return;
     }
     if (m->type != VMK_MAT_PRINCIPLED) { l = mc.single; return; }
@@ -838,7 +856,7 @@ VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sa
         float sum_weights = 0.f;
         for (int i = 0; i < mc.n; ++i) {
             float sw;
-            if (mc.m->type == VMK_MAT_MIX) sw = i == 0 ? mc.mixw[0] : mc.mixw[1];
+            if (mc.m->type == VMK_MAT_MIX || mc.m->type == VMK_MAT_ADD) sw = i == 0 ? mc.mixsw[0] : mc.mixsw[1];
             else { int k = i + mc.first; sw = k == 0 ? mc.sw[0] : k == 1 ? mc.sw[1] : k == 2 ? mc.sw[2] : k == 3 ? mc.sw[3] : k == 4 ? mc.sw[4] : mc.sw[5]; }
             strategy = uc > sum_weights ? i : strategy;
             sum_weights += sw;

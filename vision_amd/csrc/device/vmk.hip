@@ -875,12 +875,12 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     auto slot_ok = [&](const vmk_slot &s) { return s.tex == VMK_INVALID || (s.tex & 0xffffu) < sc->n_textures; };
     for (uint32_t i = 0; i < sc->n_materials; ++i) {
         const vmk_material &m = sc->materials[i];
-        if (m.type > VMK_MAT_MIX) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
+        if (m.type > VMK_MAT_ADD) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
         for (auto &s : m.slot) if (!slot_ok(s)) { ctx->error = "vmk_upload_scene: material slot references a missing texture"; return VMK_ERR_ARG; }
-        if (m.type == VMK_MAT_MIX) {
+        if (m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD) {
             if (m.child0 >= sc->n_materials || m.child1 >= sc->n_materials) { ctx->error = "vmk_upload_scene: mix child out of range"; return VMK_ERR_ARG; }
             uint32_t t0 = sc->materials[m.child0].type, t1 = sc->materials[m.child1].type;
-            if (t0 >= VMK_MAT_PRINCIPLED || t1 >= VMK_MAT_PRINCIPLED) { ctx->error = "vmk_upload_scene: mix children must be single-lobe materials"; return VMK_ERR_UNSUPPORTED; }
+            if (!VMK_MAT_IS_SINGLE_LOBE(t0) || !VMK_MAT_IS_SINGLE_LOBE(t1)) { ctx->error = "vmk_upload_scene: mix / add children must be single-lobe materials"; return VMK_ERR_UNSUPPORTED; }
         }
         if (m.type == VMK_MAT_PRINCIPLED && !sc->luts.sheen_approx && (m.slot[VMK_P_SHEEN_WEIGHT].tex != VMK_INVALID || m.slot[VMK_P_SHEEN_WEIGHT].v[0] != 0.f)) { ctx->error = "vmk_upload_scene: sheen needs the LTC tables"; return VMK_ERR_UNSUPPORTED; }
     }
@@ -911,7 +911,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     if (!sc->luts.pure_reflection || !sc->luts.dielectric || !sc->luts.dielectric_inv || !sc->luts.specular || !sc->luts.coat) { ctx->error = "vmk_upload_scene: albedo tables missing"; return VMK_ERR_ARG; }
 
     ctx->full_materials = false;
-    for (uint32_t i = 0; i < sc->n_materials; ++i) if (sc->materials[i].type >= VMK_MAT_PRINCIPLED) ctx->full_materials = true;
+    for (uint32_t i = 0; i < sc->n_materials; ++i) if (!VMK_MAT_IS_SINGLE_LOBE(sc->materials[i].type)) ctx->full_materials = true;
     if (const char *v = getenv("VMK_FORCE_FULL")) if (v[0] == '1') ctx->full_materials = true;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -405,12 +405,16 @@ struct HostScene {
             m.slot[VMK_P_COAT_IOR] = parse_slot(p, "coat_ior", 1, {1.5f}); m.slot[VMK_P_COAT_TINT] = parse_slot(p, "coat_tint", 3, {1, 1, 1});
             m.slot[VMK_P_SSS_WEIGHT] = parse_slot(p, "subsurface_weight", 1, {0.3f}); m.slot[VMK_P_SSS_RADIUS] = parse_slot(p, "subsurface_radius", 3, {1, 1, 1});
             m.slot[VMK_P_SSS_SCALE] = parse_slot(p, "subsurface_scale", 1, {0.2f}); m.slot[VMK_P_TRANS_WEIGHT] = parse_slot(p, "transmission_weight", 1, {0.f});
-        } else if (type == "mix") { // mix.cpp:27-41
-            m.type = VMK_MAT_MIX;
+        } else if (type == "metallic") { // metallic.cpp:24-34
+            m.type = VMK_MAT_METALLIC;
+            m.slot[0] = parse_slot(p, "color", 3, {1, 1, 1}); m.slot[1] = parse_slot(p, "edge_tint", 3, {1, 1, 1});
+            m.slot[2] = parse_slot(p, "roughness", 1, {0.5f}); m.slot[3] = parse_slot(p, "anisotropic", 1, {0.f});
+        } else if (type == "mix" || type == "add") { // mix.cpp:27-41, add.cpp:17-27
+            m.type = type == "mix" ? VMK_MAT_MIX : VMK_MAT_ADD;
             uint32_t c0 = add_material(p["mat0"]), c1 = add_material(p["mat1"]);
-            if (materials[c0].type == VMK_MAT_MIX || materials[c1].type == VMK_MAT_MIX) fail("material '" + name + "': nested mix is outside the hot-path scope");
+            if (!VMK_MAT_IS_SINGLE_LOBE(materials[c0].type) || !VMK_MAT_IS_SINGLE_LOBE(materials[c1].type)) fail("material '" + name + "': " + type + " of lobe-set materials (principled_bsdf / mix / add) is outside the hot-path scope");
             m.child0 = c0; m.child1 = c1;
-            m.slot[0] = parse_slot(p, "frac", 1, {0.5f});
+            if (type == "mix") m.slot[0] = parse_slot(p, "frac", 1, {0.5f});
         } else fail("material type '" + type + "' (" + name + ") is outside the hot-path scope (SURVEY.md §2)");
         describe("material", type, name);
         materials.push_back(m);
