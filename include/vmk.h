@@ -65,10 +65,11 @@ typedef enum vmk_material_type {
     VMK_MAT_PRINCIPLED = 5, /* "principled_bsdf"  principled_bsdf.cpp:352-461, 18 slots in declaration order */
     VMK_MAT_MIX = 6,        /* "mix"              mix.cpp:66-71       slot: frac; children child0/child1 */
     VMK_MAT_METALLIC = 7,   /* "metallic"         metallic.cpp:24-60  slots: color, edge_tint, roughness, anisotropic (F82-tint conductor) */
-    VMK_MAT_ADD = 8         /* "add"              add.cpp:9-60        children child0/child1, LobeSet::create_add (lobe.cpp:510-522) */
+    VMK_MAT_ADD = 8,        /* "add"              add.cpp:9-60        children child0/child1, LobeSet::create_add (lobe.cpp:510-522) */
+    VMK_MAT_PLASTIC = 9     /* "plastic"          plastic.cpp:11-131  slots: color, spec, ior, roughness, anisotropic */
 } vmk_material_type;
 /* single-lobe types may be children of mix / add */
-#define VMK_MAT_IS_SINGLE_LOBE(t) ((t) <= VMK_MAT_SUBSTRATE || (t) == VMK_MAT_METALLIC)
+#define VMK_MAT_IS_SINGLE_LOBE(t) ((t) <= VMK_MAT_SUBSTRATE || (t) == VMK_MAT_METALLIC || (t) == VMK_MAT_PLASTIC)
 
 enum { /* principled slot indices, principled_bsdf.cpp:235-256 */
     VMK_P_COLOR = 0, VMK_P_METALLIC, VMK_P_IOR, VMK_P_ROUGHNESS, VMK_P_SPEC_TINT, VMK_P_ANISOTROPIC, VMK_P_OPACITY,

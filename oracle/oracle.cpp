@@ -571,7 +571,7 @@ struct ScatterEval { float3 f{0, 0, 0}; float pdf{0.f}; uint32_t flags{flag::Uns
 struct BSDFSample { ScatterEval eval; float3 wi{0, 0, 0}; float eta{1.f}; bool valid() const { return eval.valid(); } };
 struct SampledDirection { float3 wi{0, 0, 0}; bool valid{true}; };
 
-enum LobeKind { LB_LAMBERT, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_DIELECTRIC, LB_SHEEN };
+enum LobeKind { LB_LAMBERT, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_DIELECTRIC, LB_SHEEN, LB_PLASTIC };
 struct Lobe {
     int kind{LB_LAMBERT};
     Frame frame;
@@ -665,6 +665,15 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
             se.flags = flag::Reflection;
             return se;
         }
+        case LB_PLASTIC: { // PlasticLobe::evaluate_local_impl plastic.cpp:31-43 (no hemisphere test of its own)
+            float3 wh = normalize(wo + wi);
+            float3 F = l.fr.evaluate(abs_dot(wh, wo));
+            se.f = (l.kr * InvPi) * (1.f - F);
+            se.f += BRDF_div_fr(wo, wh, wi, l.ax, l.ay) * F;
+            se.pdf = lerp_(average(F), cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
+            se.flags = flag::GlossyRefl;
+            return se;
+        }
         case LB_DIELECTRIC: { // lobe.cpp:321-412
             bool refl = same_hemisphere(wo, wi);
             float eta = l.fr.eta;
@@ -736,6 +745,14 @@ inline SampledDirection sample_wi_local(const Lobe &l, float3 wo, Sampler &sampl
                 sd.wi.z = wo.z < 0.f ? -sd.wi.z : sd.wi.z;
             }
             sd.valid = true;
+            return sd;
+        }
+        case LB_PLASTIC: { // PlasticLobe::sample_wi_local_impl plastic.cpp:45-59: 2 + 1 draws, 2 more on the diffuse branch
+            float3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
+            float3 F = l.fr.evaluate(abs_cos_theta(wo));
+            float uc = sampler.next_1d();
+            if (uc < average(F)) { sd.wi = reflect(wo, wh); sd.valid = same_hemisphere(wo, sd.wi); }
+            else sd.wi = square_to_cosine_hemisphere(sampler.next_2d());
             return sd;
         }
         case LB_DIELECTRIC: { // lobe.cpp:431-449
@@ -875,6 +892,18 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
             microfacet_alpha(s, m, 2, 3, it.uv, 0.0001f, &l.ax, &l.ay);
             l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot3(s, m.slot[0], it.uv); l.fr.b = eval_slot3(s, m.slot[1], it.uv);
             l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
+            break;
+        }
+        case VMK_MAT_PLASTIC: { // plastic.cpp:103-122 (same double roughness_to_alpha as substrate)
+            l.kind = LB_PLASTIC;
+            l.kr = eval_slot3(s, m.slot[0], it.uv);
+            float3 Rs = eval_slot3(s, m.slot[1], it.uv);
+            float ior = eval_slot1(s, m.slot[2], it.uv);
+            float ax, ay; microfacet_alpha(s, m, 3, 4, it.uv, 0.0001f, &ax, &ay);
+            if (m.flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
+            l.ax = clamp_(ax, 0.0001f, 1.f); l.ay = clamp_(ay, 0.0001f, 1.f);
+            l.fr.kind = FR_SCHLICK; l.fr.a = schlick_F0_from_ior(ior) * Rs; l.fr.eta = ior;
+            l.bxdf_flags = flag::GlossyRefl;
             break;
         }
         case VMK_MAT_METALLIC: { // metallic.cpp:42-60: MetallicLobe = PureReflectionLobe with compensation, F82-tint Fresnel
@@ -1268,6 +1297,7 @@ inline float3 lobe_albedo(const vmk_scene *s, const Lobe &l, float cos_theta) {
             if (l.albedo_lut == 2) { float sv; sample_lut3d(s->luts.specular, 1, make_float3(l.lut_x, cos_theta, l.lut_z), &sv); return lerp3(sv, l.fr.a, make_float3(1.f)) * l.kr; }
             return l.kr * l.fr.evaluate(cos_theta); // MicrofacetLobe::albedo lobe.cpp:208-210
         }
+        case LB_PLASTIC: return l.fr.evaluate(cos_theta); // MicrofacetLobe::albedo with the specular bxdf's kr = 1 (plastic.cpp:119)
         case LB_DIELECTRIC: { float3 F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; } // lobe.cpp:308-313
         default: return l.kr; // sheen: its directional albedo is folded into kr at build time (principled_bsdf.cpp:54-57)
     }

@@ -361,7 +361,7 @@ constexpr uint32_t DiffRefl = Diffuse | Reflection, GlossyRefl = Glossy | Reflec
 }
 struct ScatterEval { V3 f; float pdf; uint32_t flags; };
 struct BSDFSample { ScatterEval eval; V3 wi; float eta; };
-enum : int { LB_LAMBERT = 0, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_DIELECTRIC, LB_SHEEN };
+enum : int { LB_LAMBERT = 0, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_DIELECTRIC, LB_SHEEN, LB_PLASTIC };
 struct Lobe {
     int kind;
     V3 kr, rs;
@@ -443,6 +443,15 @@ VD ScatterEval eval_local(const DScene &S, const Lobe &l, V3 wo, V3 wi, float *e
             se.flags = flag::Reflection;
             break;
         }
+        case LB_PLASTIC: { // PlasticLobe::evaluate_local_impl plastic.cpp:31-43 (no hemisphere test of its own)
+            V3 wh = normalize(wo + wi);
+            V3 F = l.fr.evaluate(abs_dot(wh, wo));
+            se.f = (l.kr * InvPi) * (1.f - F);
+            se.f += BRDF_div_fr(wo, wh, wi, l.ax, l.ay) * F;
+            se.pdf = lerp_(average(F), cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
+            se.flags = flag::GlossyRefl;
+            break;
+        }
         case LB_DIELECTRIC: { // lobe.cpp:321-412
             bool refl = same_hemisphere(wo, wi);
             float eta = l.fr.eta;
@@ -512,6 +521,14 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
                 wi = square_to_cosine_hemisphere(u);
                 wi.z = wo.z < 0.f ? -wi.z : wi.z;
             }
+            break;
+        }
+        case LB_PLASTIC: { // PlasticLobe::sample_wi_local_impl plastic.cpp:45-59: 2 + 1 draws, 2 more on the diffuse branch
+            V3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
+            V3 F = l.fr.evaluate(abs_cos_theta(wo));
+            float uc = sampler.next_1d();
+            if (uc < average(F)) { wi = reflect(wo, wh); *valid = same_hemisphere(wo, wi); }
+            else wi = square_to_cosine_hemisphere(sampler.next_2d());
             break;
         }
         case LB_DIELECTRIC: { // lobe.cpp:431-449
@@ -598,6 +615,17 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
             microfacet_alpha(S, m, 2, 3, it.uv, 0.0001f, &l.ax, &l.ay, cnt);
             l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot3(S, m->slot[0], it.uv, cnt); l.fr.b = eval_slot3(S, m->slot[1], it.uv, cnt);
             l.compensate = true;
+            break;
+        }
+        case VMK_MAT_PLASTIC: { // plastic.cpp:103-122 (same double roughness_to_alpha as substrate)
+            l.kind = LB_PLASTIC;
+            l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            V3 Rs = eval_slot3(S, m->slot[1], it.uv, cnt);
+            float ior = eval_slot1(S, m->slot[2], it.uv, cnt);
+            float ax, ay; microfacet_alpha(S, m, 3, 4, it.uv, 0.0001f, &ax, &ay, cnt);
+            if (m->flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
+            l.ax = clamp_(ax, 0.0001f, 1.f); l.ay = clamp_(ay, 0.0001f, 1.f);
+            l.fr.kind = FR_SCHLICK; l.fr.a = schlick_F0_from_ior(ior) * Rs; l.fr.eta = ior;
             break;
         }
         case VMK_MAT_METALLIC: { // metallic.cpp:42-60: MetallicLobe = PureReflectionLobe with compensation, F82-tint Fresnel
@@ -803,6 +831,7 @@ VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, const Lobe &l, float
             return l.kr * l.fr.evaluate(cos_theta);
         }
         case LB_DIELECTRIC: { V3 F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; }
+        case LB_PLASTIC: return l.fr.evaluate(cos_theta); // MicrofacetLobe::albedo with the specular bxdf's kr = 1 (plastic.cpp:119)
         default: return l.kr; // Lambert / Oren-Nayar / FresnelBlend Rd / sheen (albedo folded into kr at build time)
     }
 }

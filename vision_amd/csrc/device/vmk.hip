@@ -875,7 +875,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     auto slot_ok = [&](const vmk_slot &s) { return s.tex == VMK_INVALID || (s.tex & 0xffffu) < sc->n_textures; };
     for (uint32_t i = 0; i < sc->n_materials; ++i) {
         const vmk_material &m = sc->materials[i];
-        if (m.type > VMK_MAT_ADD) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
+        if (m.type > VMK_MAT_PLASTIC) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
         for (auto &s : m.slot) if (!slot_ok(s)) { ctx->error = "vmk_upload_scene: material slot references a missing texture"; return VMK_ERR_ARG; }
         if (m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD) {
             if (m.child0 >= sc->n_materials || m.child1 >= sc->n_materials) { ctx->error = "vmk_upload_scene: mix child out of range"; return VMK_ERR_ARG; }

@@ -405,6 +405,11 @@ struct HostScene {
             m.slot[VMK_P_COAT_IOR] = parse_slot(p, "coat_ior", 1, {1.5f}); m.slot[VMK_P_COAT_TINT] = parse_slot(p, "coat_tint", 3, {1, 1, 1});
             m.slot[VMK_P_SSS_WEIGHT] = parse_slot(p, "subsurface_weight", 1, {0.3f}); m.slot[VMK_P_SSS_RADIUS] = parse_slot(p, "subsurface_radius", 3, {1, 1, 1});
             m.slot[VMK_P_SSS_SCALE] = parse_slot(p, "subsurface_scale", 1, {0.2f}); m.slot[VMK_P_TRANS_WEIGHT] = parse_slot(p, "transmission_weight", 1, {0.f});
+        } else if (type == "plastic") { // plastic.cpp:88-96
+            m.type = VMK_MAT_PLASTIC;
+            m.slot[0] = parse_slot(p, "color", 3, {1, 1, 1}); m.slot[1] = parse_slot(p, "spec", 3, {0.05f, 0.05f, 0.05f});
+            m.slot[2] = parse_slot(p, "ior", 1, {1.3f});
+            m.slot[3] = parse_slot(p, "roughness", 1, {0.5f}); m.slot[4] = parse_slot(p, "anisotropic", 1, {0.f});
         } else if (type == "metallic") { // metallic.cpp:24-34
             m.type = VMK_MAT_METALLIC;
             m.slot[0] = parse_slot(p, "color", 3, {1, 1, 1}); m.slot[1] = parse_slot(p, "edge_tint", 3, {1, 1, 1});
