@@ -7,8 +7,8 @@
 //
 // Pinning: the ocarina submodule (DSL/RHI/OptiX layer) is absent from the reference checkout, so everything
 // that crosses into it (omath.h) is "parity unpinned".  The lobe / microfacet / Fresnel code is pinned by
-// re-integrating the reference's own precomputed albedo tables (tests/golden/lut_*.json, extracted from
-// base/scattering/precomputed_table.h by tools/make_golden_luts.py) — see tests/test_oracle_luts.py.
+// re-integrating the reference's own precomputed albedo tables (tests/golden/lut_subgrid.json, extracted from
+// base/scattering/precomputed_table.h by tools/make_golden_luts.py) — see tests/test_oracle_golden.py.
 #include "omath.h"
 #include "../include/vmk.h"
 
