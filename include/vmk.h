@@ -336,6 +336,11 @@ int vmk_precompute_albedo(vmk_ctx *ctx, uint32_t which, uint32_t res, uint32_t s
 int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out,
                   uint32_t out_stride);
 
+/* Toolchain self-check: renders frame 0 of up to max_pixels (0 = 4096) strided pixels with the megakernel variant the
+ * scene selects and with the unit kernel (a separately compiled instance of the same path code) and compares the
+ * radiance bit for bit.  Returns VMK_OK when they agree; the user's framebuffer and counters are left untouched. */
+int vmk_self_check(vmk_ctx *ctx, uint32_t max_pixels, uint32_t *n_checked, uint32_t *n_mismatch);
+
 #ifdef __cplusplus
 }
 #endif

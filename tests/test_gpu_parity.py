@@ -108,6 +108,7 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog"))
+    assert backend.self_check() == w * h  # the megakernel variant this scene selects agrees with the unit kernel (vmk_self_check)
     backend.reset_accum(); backend.reset_counters()
     backend.render_batch(0, spp)
     img = backend.download_accum()

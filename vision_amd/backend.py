@@ -51,6 +51,7 @@ def lib():
         L.vmk_accel_info_get.argtypes = [C.c_void_p, C.c_void_p]
         L.vmk_trace_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.POINTER(C.c_float), C.c_uint32]
+        L.vmk_self_check.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.vmk_render_aov.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmk_precompute_albedo.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.vmk_test_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
@@ -146,6 +147,12 @@ class Backend:
         out = np.zeros((inp.shape[0], out_stride), np.float32)
         self._check(self._L.vmk_test_eval(self._h, kind, inp.shape[0], _ptr(inp), inp.shape[1], _ptr(out), out_stride))
         return out
+
+    def self_check(self, max_pixels=0):
+        """vmk_self_check: megakernel variant vs unit kernel on frame 0 of a pixel subset; raises BackendError on a mismatch."""
+        n, bad = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.vmk_self_check(self._h, max_pixels, C.byref(n), C.byref(bad)))
+        return n.value
 
     def render_aov(self, frame=0):
         """Primary-hit AOV planes of `frame` (include/vmk.h: vmk_render_aov): dict normal / albedo / emission [H, W, 4], depth [H, W]."""

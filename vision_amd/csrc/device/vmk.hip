@@ -1350,4 +1350,61 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     return VMK_OK;
 }
 
+// Cross-check of two independently compiled instances of the path code: frame 0 of a strided subset of pixels is rendered
+// by the megakernel variant this scene selects (k_render<FULL, MEDIA>, its own register budget) and stepped by k_test kind 6
+// (path_bounce<true, true> at 128 registers); the radiance must agree bit for bit.  A difference means the toolchain
+// produced inconsistent code for one of them (seen twice during development on 96-register variants).
+int vmk_self_check(vmk_ctx *ctx, uint32_t max_pixels, uint32_t *n_checked, uint32_t *n_mismatch) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!ctx->accel_ready || !ctx->params_ready || !ctx->fb) { ctx->error = "vmk_self_check: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    if (n_checked) *n_checked = 0;
+    if (n_mismatch) *n_mismatch = 0;
+    const uint32_t w = ctx->params.width, h = ctx->params.height;
+    const size_t n_pix = (size_t) w * h;
+    if (max_pixels == 0) max_pixels = 4096;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // 1. frame 0 through the megakernel into a scratch film (acc = lerp(1, 0, L) = L), counters preserved
+    DevBuf<float4> film;
+    unsigned long long saved[8];
+    HIP_TRY(hipMemcpyAsync(saved, ctx->counters.p, sizeof(saved), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipError_t e = film.alloc(n_pix);
+    if (e != hipSuccess) { ctx->error = std::string("vmk_self_check: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    float4 *user_fb = ctx->fb;
+    ctx->fb = film.p;
+    int rc = vmk_reset_accum(ctx);
+    if (rc == VMK_OK) rc = vmk_render_batch(ctx, 0, 1, nullptr, nullptr);
+    std::vector<float> img(n_pix * 4);
+    if (rc == VMK_OK) rc = vmk_download_accum(ctx, img.data());
+    ctx->fb = user_fb;
+    film.release();
+    (void) hipMemcpyAsync(ctx->counters.p, saved, sizeof(saved), hipMemcpyHostToDevice, ctx->stream);
+    (void) hipStreamSynchronize(ctx->stream);
+    if (rc != VMK_OK) return rc;
+    // 2. the same paths through the unit kernel
+    const size_t stride = std::max<size_t>(1, (n_pix + max_pixels - 1) / max_pixels);
+    std::vector<uint32_t> idx;
+    for (size_t p = 0; p < n_pix; p += stride) idx.push_back((uint32_t) p);
+    std::vector<float> in(idx.size() * 3), out(idx.size() * 67);
+    for (size_t k = 0; k < idx.size(); ++k) {
+        uint32_t v[3] = {idx[k] % w, idx[k] / w, 0u};
+        std::memcpy(&in[k * 3], v, 12);
+    }
+    rc = vmk_test_eval(ctx, 6, (uint32_t) idx.size(), in.data(), 3, out.data(), 67);
+    (void) hipMemcpyAsync(ctx->counters.p, saved, sizeof(saved), hipMemcpyHostToDevice, ctx->stream);
+    (void) hipStreamSynchronize(ctx->stream);
+    if (rc != VMK_OK) return rc;
+    uint32_t bad = 0;
+    for (size_t k = 0; k < idx.size(); ++k)
+        for (int c = 0; c < 3; ++c) {
+            float a = img[(size_t) idx[k] * 4 + c], b = out[k * 67 + 64 + c];
+            uint32_t ua, ub; std::memcpy(&ua, &a, 4); std::memcpy(&ub, &b, 4);
+            if (ua != ub && !(a != a && b != b)) { ++bad; break; }
+        }
+    if (n_checked) *n_checked = (uint32_t) idx.size();
+    if (n_mismatch) *n_mismatch = bad;
+    if (bad) { ctx->error = "vmk_self_check: " + std::to_string(bad) + " of " + std::to_string(idx.size()) + " pixels differ between the megakernel and the unit kernel"; return VMK_ERR_STATE; }
+    return VMK_OK;
+}
+
 }// extern "C"

@@ -108,12 +108,15 @@ class Pipeline:
         self._prepared = False
 
     # ---- FixedRenderPipeline::prepare (fixed/pipeline.cpp:14-23): upload + build accel ----
-    def prepare(self):
+    def prepare(self, self_check=None):
         self.backend.upload_scene(self.host_scene)
         self.accel_info = self.backend.build_accel()
         self.backend.set_render_params(self.params)
         self.integrator.prepare()
         self._prepared = True
+        # optional toolchain self-check (megakernel variant vs unit kernel, include/vmk.h): on by argument or VMK_SELF_CHECK=1
+        if self_check if self_check is not None else os.environ.get("VMK_SELF_CHECK") == "1":
+            self.backend.self_check()
 
     def compile(self):
         self.integrator.compile()
