@@ -78,6 +78,7 @@ def main():
 
     pipe = Pipeline(a.scene, device=local_rank, width=a.width, height=a.height)
     pipe.prepare()
+    checked = pipe.backend.self_check()  # the megakernel variant about to be timed agrees bit for bit with the unit kernel (raises otherwise)
     params = pipe.params
     pixels = params.width * params.height
     dev = torch.device("cuda", local_rank)
@@ -143,6 +144,7 @@ def main():
             "config": {"workload": f"classroom {params.width}x{params.height}, max_depth {params.max_depth}, min_depth {params.min_depth}, "
                                    f"{spp} spp per step x {a.steps} steps = {spp * a.steps} spp, env-lit, box filter",
                        "triangles": int(sc.n_tris), "spp_per_step": spp, "tile": a.tile, "parallelism": f"tiles/{world}"},
+            "self_check": f"megakernel == unit kernel on {checked} pixels of frame 0 (bit-exact)",
             "rays_per_path": rays / max(c_all["paths"], 1),
             "nodes_per_ray": c_all["nodes_visited"] / max(rays, 1), "tris_per_ray": c_all["tris_tested"] / max(rays, 1),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
