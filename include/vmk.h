@@ -314,10 +314,11 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
 /* ---- AOV pass (FrameBuffer::compile_compute_geom, src/base/sensor/frame_buffer.cpp:156-219) -----------------
  * Primary-hit planes of frame `frame` for denoisers / image tooling: shading normal (w = 1 on a hit, 0 on a
  * miss), MaterialEvaluator::albedo (material.cpp:91-98), emitted radiance (evaluate_hit_wi), each width*height
- * RGBA floats, and linear depth = (world-to-camera * p).z (sensor.cpp:192-195), width*height floats.  Any output
- * may be NULL.  Motion vectors are not produced (static camera per render). */
+ * RGBA floats, linear depth = (world-to-camera * p).z (sensor.cpp:192-195), width*height floats, and the motion
+ * vector p_film - prev_raster_coord(p) (frame_buffer.cpp:483-491, sensor.cpp:95-100; the previous camera is the
+ * current one, so this is the lens / filter reprojection offset), width*height*2 floats.  Any output may be NULL. */
 int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba,
-                   float *depth);
+                   float *depth, float *motion_xy);
 
 /* ---- albedo-table precompute (the reference's vision-precompute app, src/apps/precompute/main.cpp:24-41;
  * Material::precompute_lobe base/scattering/material.h:121-163; Lobe::integral_albedo lobe.cpp:13-33) --------

@@ -1265,9 +1265,10 @@ inline float2 filter_sample(const vmk_render_params &p, float2 u) {
     float sx = v.x > 0.f ? 1.f : (v.x < 0.f ? -1.f : 0.f), sy = v.y > 0.f ? 1.f : (v.y < 0.f ? -1.f : 0.f);
     return {fu * sx * p.filter_radius[0], fv * sy * p.filter_radius[1]};
 }
-inline Ray generate_ray(const vmk_render_params &p, uint32_t px, uint32_t py, Sampler &sampler) {
+inline Ray generate_ray(const vmk_render_params &p, uint32_t px, uint32_t py, Sampler &sampler, float2 *p_film_out = nullptr) {
     float2 fs = filter_sample(p, sampler.next_2d());
     float2 p_film = {(float) px + 0.5f + fs.x, (float) py + 0.5f + fs.y};
+    if (p_film_out) *p_film_out = p_film;
     float2 p_lens_u = sampler.next_2d();
     (void) sampler.next_1d(); // time
     float3 p_sensor = transform_point4(p.raster_to_sensor, make_float3(p_film.x, p_film.y, 0.f));
@@ -1302,18 +1303,25 @@ inline float3 lobe_albedo(const vmk_scene *s, const Lobe &l, float cos_theta) {
         default: return l.kr; // sheen: its directional albedo is folded into kr at build time (principled_bsdf.cpp:54-57)
     }
 }
-struct PixelAov { float3 normal, albedo, emission; float depth; bool hit; };
-inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const float *w2c, uint32_t px, uint32_t py, uint32_t frame) {
-    PixelAov a{make_float3(0.f), make_float3(0.f), make_float3(0.f), 0.f, false};
+struct PixelAov { float3 normal, albedo, emission; float depth; float2 motion; bool hit; };
+inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const float *w2c, const float *s2r, uint32_t px, uint32_t py, uint32_t frame) {
+    PixelAov a{make_float3(0.f), make_float3(0.f), make_float3(0.f), 0.f, make_float2(0.f, 0.f), false};
     const vmk_scene *s = sv.s;
     Sampler sampler; sampler.start(px, py, frame, 0);
-    Ray ray = generate_ray(p, px, py, sampler);
+    float2 p_film;
+    Ray ray = generate_ray(p, px, py, sampler, &p_film);
     Hit hit = sv.trace_closest(ray);
     if (hit.is_miss()) return a;
     a.hit = true;
     Interaction it = compute_surface_interaction(s, hit, ray);
     a.normal = it.shading.z;
     a.depth = w2c[2] * it.pos.x + w2c[6] * it.pos.y + w2c[10] * it.pos.z + w2c[14]; // transform_point(w2c, pos).z, column-major
+    { // compute_motion_vec (frame_buffer.cpp:483-491) against Sensor::prev_raster_coord (sensor.cpp:95-100); prev == current camera
+        float3 ps = transform_point4(w2c, it.pos);
+        ps = ps / ps.z;
+        float3 rc = transform_point4(s2r, ps);
+        a.motion = make_float2(p_film.x - rc.x, p_film.y - rc.y);
+    }
     if (it.has_material()) {
         LobeSet lobes; build_lobe_set(s, s->materials[it.mat_id], it, lobes);
         float cos_theta = dot(it.shading.z, it.wo);
@@ -1585,16 +1593,17 @@ uint32_t orc_dump_rays(void *h, const vmk_render_params *p, uint32_t frame, uint
 
 // AOV planes of frame `frame` (frame_buffer.cpp:156-219): any output may be null.  normal/albedo/emission are RGBA (w = 1 like
 // the reference's buffers), depth one float per pixel; misses leave zeros.
-int orc_render_aov(void *h, const vmk_render_params *p, const float *w2c, uint32_t frame, float *normal, float *albedo, float *emission, float *depth) {
+int orc_render_aov(void *h, const vmk_render_params *p, const float *w2c, const float *s2r, uint32_t frame, float *normal, float *albedo, float *emission, float *depth, float *motion) {
     SceneView &sv = ((orc_scene_handle *) h)->sv;
     for (uint32_t y = 0; y < p->height; ++y)
         for (uint32_t x = 0; x < p->width; ++x) {
-            PixelAov a = primary_aov(sv, *p, w2c, x, y, frame);
+            PixelAov a = primary_aov(sv, *p, w2c, s2r, x, y, frame);
             size_t i = (size_t) y * p->width + x;
             if (normal) { normal[4 * i] = a.normal.x; normal[4 * i + 1] = a.normal.y; normal[4 * i + 2] = a.normal.z; normal[4 * i + 3] = a.hit ? 1.f : 0.f; }
             if (albedo) { albedo[4 * i] = a.albedo.x; albedo[4 * i + 1] = a.albedo.y; albedo[4 * i + 2] = a.albedo.z; albedo[4 * i + 3] = 1.f; }
             if (emission) { emission[4 * i] = a.emission.x; emission[4 * i + 1] = a.emission.y; emission[4 * i + 2] = a.emission.z; emission[4 * i + 3] = 1.f; }
             if (depth) depth[i] = a.depth;
+            if (motion) { motion[2 * i] = a.motion.x; motion[2 * i + 1] = a.motion.y; }
         }
     sv.flush_thread_counters();
     return 0;

@@ -42,7 +42,7 @@ def lib():
         L.orc_test_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                     C.c_void_p, C.c_uint32]
         L.orc_integrate_albedo.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
-        L.orc_render_aov.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_render_aov.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_dump_rays.restype = C.c_uint32
         L.orc_dump_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         _LIB = L
@@ -86,8 +86,12 @@ class OracleScene:
         c2w = np.array(params.c2w, np.float64).reshape(4, 4).T  # column-major storage
         w2c = np.ascontiguousarray(np.linalg.inv(c2w).T.astype(np.float32)).reshape(-1)  # back to column-major floats
         out = {k: np.zeros((h, w, 4), np.float32) for k in ("normal", "albedo", "emission")}
+        r2s = np.array(params.raster_to_sensor, np.float64).reshape(4, 4).T
+        s2r = np.ascontiguousarray(np.linalg.inv(r2s).T.astype(np.float32)).reshape(-1)
         out["depth"] = np.zeros((h, w), np.float32)
-        lib().orc_render_aov(self._h, C.byref(params), _ptr(w2c), frame, _ptr(out["normal"]), _ptr(out["albedo"]), _ptr(out["emission"]), _ptr(out["depth"]))
+        out["motion"] = np.zeros((h, w, 2), np.float32)
+        lib().orc_render_aov(self._h, C.byref(params), _ptr(w2c), _ptr(s2r), frame, _ptr(out["normal"]), _ptr(out["albedo"]), _ptr(out["emission"]),
+                             _ptr(out["depth"]), _ptr(out["motion"]))
         return out
 
     def dump_rays(self, params, frame=0, stride=1):

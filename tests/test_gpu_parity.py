@@ -275,6 +275,9 @@ def test_aov_planes_match_oracle(backend, scene, w, h, kw):
     for k in ("normal", "albedo", "emission"):
         assert _bits_equal(g[k], o[k]), k
     assert np.allclose(g["depth"], o["depth"], rtol=2e-6, atol=1e-6)  # the two sides invert the camera matrix independently
+    assert np.allclose(g["motion"], o["motion"], atol=2e-3)  # reprojection through two independently inverted matrices (pixels)
+    hit = g["normal"][..., 3] == 1.0
+    assert np.abs(g["motion"][hit]).max() < 0.05 and (g["motion"][~hit] == 0).all()  # static camera: only the lens / rounding offset remains
     assert (g["normal"][..., 3] == 1.0).mean() > 0.5
 
 

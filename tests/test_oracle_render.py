@@ -107,6 +107,7 @@ def test_oracle_aov_planes_are_consistent(built):
     assert hit.mean() > 0.9
     assert np.allclose(np.linalg.norm(a["normal"][hit][:, :3], axis=1), 1.0, atol=1e-5)
     assert (a["depth"][hit] > 0).all() and (a["depth"][~hit] == 0).all()
+    assert np.abs(a["motion"][hit]).max() < 0.05 and (a["motion"][~hit] == 0).all()  # static pinhole camera: reprojection lands on p_film
     lit = a["emission"][..., :3].sum(-1) > 0
     assert 0 < lit.sum() < hit.sum() * 0.2
     # every material of cbox_matte is diffuse: albedo in [0, 1], and the distinct albedo values are the scene's colours

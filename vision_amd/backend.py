@@ -52,7 +52,7 @@ def lib():
         L.vmk_trace_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.POINTER(C.c_float), C.c_uint32]
         L.vmk_self_check.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-        L.vmk_render_aov.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vmk_render_aov.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmk_precompute_albedo.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.vmk_test_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         if L.vmk_abi_version() != _abi.ABI_VERSION:
@@ -155,11 +155,13 @@ class Backend:
         return n.value
 
     def render_aov(self, frame=0):
-        """Primary-hit AOV planes of `frame` (include/vmk.h: vmk_render_aov): dict normal / albedo / emission [H, W, 4], depth [H, W]."""
+        """Primary-hit AOV planes of `frame` (include/vmk.h: vmk_render_aov): dict normal / albedo / emission [H, W, 4], depth [H, W], motion [H, W, 2]."""
         h, w = self.params.height, self.params.width
         out = {k: np.zeros((h, w, 4), np.float32) for k in ("normal", "albedo", "emission")}
         out["depth"] = np.zeros((h, w), np.float32)
-        self._check(self._L.vmk_render_aov(self._h, frame, _ptr(out["normal"]), _ptr(out["albedo"]), _ptr(out["emission"]), _ptr(out["depth"])))
+        out["motion"] = np.zeros((h, w, 2), np.float32)
+        self._check(self._L.vmk_render_aov(self._h, frame, _ptr(out["normal"]), _ptr(out["albedo"]), _ptr(out["emission"]), _ptr(out["depth"]),
+                                           _ptr(out["motion"])))
         return out
 
     def precompute_albedo(self, which, res=32, samples=1 << 17):

@@ -1120,9 +1120,10 @@ VD V2 filter_sample(const vmk_render_params *P, V2 u) {
     float sx = v.x > 0.f ? 1.f : (v.x < 0.f ? -1.f : 0.f), sy = v.y > 0.f ? 1.f : (v.y < 0.f ? -1.f : 0.f);
     return {fu * sx * P->filter_radius[0], fv * sy * P->filter_radius[1]};
 }
-VD Ray generate_ray(const vmk_render_params *P, uint32_t px, uint32_t py, Sampler &sampler) {
+VD Ray generate_ray(const vmk_render_params *P, uint32_t px, uint32_t py, Sampler &sampler, V2 *p_film_out = nullptr) {
     V2 fs = filter_sample(P, sampler.next_2d());
     V2 p_film = {(float) px + 0.5f + fs.x, (float) py + 0.5f + fs.y};
+    if (p_film_out) *p_film_out = p_film;
     V2 p_lens_u = sampler.next_2d();
     (void) sampler.next_1d();
     V3 p_sensor = transform_point4(P->raster_to_sensor, mk3(p_film.x, p_film.y, 0.f));

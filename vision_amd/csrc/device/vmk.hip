@@ -655,8 +655,10 @@ struct AovArgs {
     const vmk_render_params *params;
     float4 *normal, *albedo, *emission; // RGBA planes or null
     float *depth;
+    float2 *motion;
     uint32_t frame;
-    float w2c_z[4]; // third row of world-to-camera
+    float w2s[16]; // inverse(c2w)              (Sensor::store_prev_data sensor.cpp:89-93; the camera is static within a render)
+    float s2r[16]; // inverse(raster_to_sensor)
 };
 __global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
@@ -670,18 +672,26 @@ __global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
         const bool live = i < n;
         const uint32_t px = live ? i % P->width : 0u, py = live ? i / P->width : 0u;
         Sampler sampler; sampler.start(px, py, A.frame, 0);
-        Ray ray = generate_ray(P, px, py, sampler);
+        V2 p_film;
+        Ray ray = generate_ray(P, px, py, sampler, &p_film);
         Hit hit;
         bool found = traverse_wave(S, ray, live, false, ws, hit, cnt);
         if (!live) continue;
         V3 normal = mk3(0.f), albedo = mk3(0.f), emission = mk3(0.f);
         float depth = 0.f;
+        V2 motion = {0.f, 0.f};
         if (found) {
             Interaction it;
             compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
             it.wo = normalize(-ray.d);
             normal = it.shading.z;
-            depth = A.w2c_z[0] * it.pos.x + A.w2c_z[1] * it.pos.y + A.w2c_z[2] * it.pos.z + A.w2c_z[3];
+            depth = A.w2s[2] * it.pos.x + A.w2s[6] * it.pos.y + A.w2s[10] * it.pos.z + A.w2s[14];
+            { // compute_motion_vec (frame_buffer.cpp:483-491) against Sensor::prev_raster_coord (sensor.cpp:95-100)
+                V3 ps = transform_point4(A.w2s, it.pos);
+                ps = ps / ps.z;
+                V3 rc = transform_point4(A.s2r, ps);
+                motion = {p_film.x - rc.x, p_film.y - rc.y};
+            }
             if (it.mat_id != VMK_INVALID) {
                 MatCtx mc;
                 mat_prepare<true>(S, S.materials + it.mat_id, it, mc, cnt);
@@ -693,6 +703,7 @@ __global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
         if (A.albedo) A.albedo[i] = make_float4(albedo.x, albedo.y, albedo.z, 1.f);
         if (A.emission) A.emission[i] = make_float4(emission.x, emission.y, emission.z, 1.f);
         if (A.depth) A.depth[i] = depth;
+        if (A.motion) A.motion[i] = make_float2(motion.x, motion.y);
     }
 }
 
@@ -1256,39 +1267,50 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     return VMK_OK;
 }
 
-int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba, float *depth) {
+// general 4x4 inverse (column-major floats in, floats out) evaluated in double; false when singular
+static bool inverse4(const float *m, float *out) {
+    double a[16], inv[16];
+    for (int i = 0; i < 16; ++i) a[i] = m[i];
+    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+    if (det == 0.0) return false;
+    for (int i = 0; i < 16; ++i) out[i] = (float) (inv[i] / det);
+    return true;
+}
+
+int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba, float *depth, float *motion_xy) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready) { ctx->error = "vmk_render_aov: scene/accel/params not ready"; return VMK_ERR_STATE; }
     if (ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_render_aov: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t) ctx->params.width * ctx->params.height;
-    DevBuf<float4> dn, da, de; DevBuf<float> dd;
-    auto cleanup = [&]() { dn.release(); da.release(); de.release(); dd.release(); };
+    DevBuf<float4> dn, da, de; DevBuf<float> dd; DevBuf<float2> dm;
+    auto cleanup = [&]() { dn.release(); da.release(); de.release(); dd.release(); dm.release(); };
     hipError_t e = hipSuccess;
     if (normal_rgba) e = dn.alloc(n);
     if (e == hipSuccess && albedo_rgba) e = da.alloc(n);
     if (e == hipSuccess && emission_rgba) e = de.alloc(n);
     if (e == hipSuccess && depth) e = dd.alloc(n);
+    if (e == hipSuccess && motion_xy) e = dm.alloc(n);
     if (e != hipSuccess) { cleanup(); ctx->error = std::string("vmk_render_aov: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
     AovArgs A{};
-    A.scene = ctx->d_scene.p; A.params = ctx->d_params.p; A.normal = dn.p; A.albedo = da.p; A.emission = de.p; A.depth = dd.p; A.frame = frame;
-    { // third row of inverse(c2w), column-major 4x4, in double (Sensor::linear_depth sensor.cpp:192-195)
-        const float *m = ctx->params.c2w;
-        double a[16], inv[16];
-        for (int i = 0; i < 16; ++i) a[i] = m[i];
-        // cofactors of the third row of the inverse = third column of the adjugate
-        inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
-        inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
-        inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
-        inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
-        inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
-        inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
-        inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
-        inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
-        double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
-        if (det == 0.0) { cleanup(); ctx->error = "vmk_render_aov: camera matrix is singular"; return VMK_ERR_ARG; }
-        A.w2c_z[0] = (float) (inv[2] / det); A.w2c_z[1] = (float) (inv[6] / det); A.w2c_z[2] = (float) (inv[10] / det); A.w2c_z[3] = (float) (inv[14] / det);
-    }
+    A.scene = ctx->d_scene.p; A.params = ctx->d_params.p; A.normal = dn.p; A.albedo = da.p; A.emission = de.p; A.depth = dd.p; A.motion = dm.p; A.frame = frame;
+    if (!inverse4(ctx->params.c2w, A.w2s) || !inverse4(ctx->params.raster_to_sensor, A.s2r)) { cleanup(); ctx->error = "vmk_render_aov: camera matrix is singular"; return VMK_ERR_ARG; }
     uint32_t grid = (uint32_t) std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * 6);
     hipLaunchKernelGGL(k_aov, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
     e = hipGetLastError();
@@ -1296,6 +1318,7 @@ int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albe
     if (e == hipSuccess && albedo_rgba) e = hipMemcpyAsync(albedo_rgba, da.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && emission_rgba) e = hipMemcpyAsync(emission_rgba, de.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && depth) e = hipMemcpyAsync(depth, dd.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && motion_xy) e = hipMemcpyAsync(motion_xy, dm.p, n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     cleanup();
     if (e != hipSuccess) { ctx->error = std::string("vmk_render_aov: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
