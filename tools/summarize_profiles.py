@@ -51,7 +51,7 @@ for l in open(os.path.join(prof, "bench_kt.log")):
     if l.startswith('{"metric"'):
         bench_line = l.strip()
 with open(os.path.join(out, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# {tag}: rocprofv3 summary of `python3 bench.py --spp-per-step {spp}` on MI355X\n\n")
+    f.write(f"# {tag}: rocprofv3 summary of `python3 bench.py --steps 2 --warmup 1 --spp-per-step {spp} --no-cpu-baseline --no-replay --no-self-check` on MI355X (tools/gpu_profile.sh)\n\n")
     f.write(f"* `--kernel-trace --stats`: k_render {kr['Calls']} calls, average {float(kr['AverageNs'])/1e6:.3f} ms (min {float(kr['MinNs'])/1e6:.3f}, max {float(kr['MaxNs'])/1e6:.3f}), {kr['Percentage']} % of GPU time — see `{tag}_kernel_stats.csv`.\n")
     f.write(f"* separate `--pmc` passes (k_render, per launch): FETCH_SIZE {fetch_kb:.4g} KB, WRITE_SIZE {write_kb:.4g} KB, L2 hit rate {res['L2_hit_rate']:.3f}.\n")
     f.write(f"* HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = {traffic/1e9:.1f} GB (uncorrected {(fetch_kb+write_kb)*1024/1e9:.1f} GB) -> {traffic/float(kr['AverageNs']):.1f} GB/s.\n")
