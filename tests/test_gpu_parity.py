@@ -380,3 +380,27 @@ def test_render_edge_cases(backend, w, h, max_depth, min_depth, tiles):
         assert cg["closest_rays"] == 0 and (img[..., :3] == 0).all()
     if tiles == (64, 5, 7):
         assert cg["paths"] == 0 and (img == 0).all()
+
+
+def test_glass_of_water_agrees_with_the_reference_render(backend):
+    """Image-level pin against the reference's OWN output: Vision ships its 1024-spp render of glass-of-water
+    (tests/golden/glass_of_water_ref_blocks.npy = 16x16 block means of that PNG, tools/make_golden_refimage.py).  Away from
+    the glass (the poured-water mesh is missing from the checkout) this backend's render agrees with it to ~2/255 per block
+    after the plain exposure + sRGB encoding that picture turns out to carry, and per-channel energy agrees within 15 %."""
+    hs, p, osc, _ = _load(backend, "scenes/glass-of-water/vision_scene.json", 1280, 720)
+    backend.reset_accum()
+    backend.render_batch(0, 128)
+    lin = backend.download_accum()[..., :3].astype(np.float64)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "glass_of_water_ref_blocks.npy")).astype(np.float64)
+    B = 16
+    blocks = lambda img: img[:720 // B * B, :1280 // B * B].reshape(720 // B, B, 1280 // B, B, 3).mean((1, 3))
+    srgb = lambda x: np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(np.maximum(x, 1e-12), 1 / 2.4) - 0.055)
+    inv_srgb = lambda y: np.where(y <= 0.04045, y / 12.92, np.power((y + 0.055) / 1.055, 2.4))
+    mask = np.ones(ref.shape[:2], bool)
+    mask[:, 24:58] = False                 # glass, water stream
+    mask[28:, 6:70] = False                # ice cubes, puddles, reflections of the stream on the table
+    mine = blocks(srgb(1.0 - np.exp(-lin)))
+    d = (mine - ref)[mask]
+    assert np.abs(d).mean() < 0.015, float(np.abs(d).mean())          # measured 0.0064
+    ratio = blocks(lin)[mask].sum(0) / inv_srgb(ref)[mask].sum(0)      # measured (0.95, 1.09, 1.09)
+    assert (ratio > 0.85).all() and (ratio < 1.15).all(), ratio
