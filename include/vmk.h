@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VMK_ABI_VERSION 3u
+#define VMK_ABI_VERSION 4u
 #define VMK_INVALID 0xFFFFFFFFu
 
 typedef enum vmk_status {
@@ -81,6 +81,7 @@ enum { /* principled slot indices, principled_bsdf.cpp:235-256 */
 
 #define VMK_MATF_REMAP_ROUGHNESS 1u /* desc["remapping_roughness"] (default true) */
 #define VMK_MATF_HAS_SIGMA 2u       /* diffuse: Oren-Nayar when "sigma" present (diffuse.cpp:24-27) */
+#define VMK_MATF_DISPERSIVE 4u      /* glass, hero spectrum: the ior slot is an "spd" node (GlassMaterial::is_dispersive glass.cpp:234) */
 
 /* A material / light parameter slot (ShaderNodeSlot, src/base/shader_graph/shader_node.cpp:242-273).
  * tex == VMK_INVALID : constant, value v[0..2] (scalar slots use v[0]).
@@ -90,6 +91,17 @@ typedef struct vmk_slot {
     float v[3];
     uint32_t tex;
 } vmk_slot;
+/* hero spectrum only — "spd" shader node (render_core/shadernode/spd.cpp:36-39): a tabulated spectrum evaluated at the
+ * path's sampled wavelengths.  tex == VMK_SLOT_SPD, v[0] / v[1] hold the BIT PATTERNS of two uint32 (first float of the
+ * table in vmk_scene.spd_data, sample count), v[2] = SPD::sample_interval_ (spd.cpp:50-53: 471 / count). */
+#define VMK_SLOT_SPD 0xFFFFFFFDu
+
+/* Spectrum plugin (src/render_core/spectrum): how colours travel along a path */
+typedef enum vmk_spectrum_type {
+    VMK_SPECTRUM_SRGB = 0, /* srgb.cpp: three fixed channels, RGB values used as they are */
+    VMK_SPECTRUM_HERO = 1  /* hero.cpp: 3 wavelengths per path (hero + 2 rotations), RGB uplifted through the sigmoid table */
+} vmk_spectrum_type;
+#define VMK_RGB2SPEC_RES 64u /* RGBToSpectrumTable::res hero.cpp:53 */
 
 typedef struct vmk_material {
     uint32_t type;  /* vmk_material_type */
@@ -204,6 +216,15 @@ typedef struct vmk_scene {
      * entry per light in lights[] order (the environment light weighs 0 when env_separate); VMK_INVALID when absent */
     uint32_t light_alias_offset;
     float light_alias_integral;
+    /* ---- spectrum (render_core/spectrum/{srgb,hero}.cpp); everything below is ignored for VMK_SPECTRUM_SRGB ---- */
+    uint32_t spectrum;          /* vmk_spectrum_type */
+    const float *rgb2spec;      /* float[3][64][64][64][4]: sigmoid-polynomial coefficients c0,c1,c2 (w unused), hero.cpp:52-76 */
+    const float *spd_data;      /* pool of tabulated spectra: the four CIE tables below + every VMK_SLOT_SPD slot */
+    uint32_t n_spd;             /* floats in spd_data */
+    uint32_t spd_cie[4];        /* first float of CIE x, y, z and illuminant D65 (SPD::create_cie_* spd.cpp:95-109) */
+    uint32_t spd_cie_count;     /* samples per CIE table (94: every 5th of the 1 nm tables) */
+    float spd_cie_interval;     /* SPD::sample_interval_ of those tables (471 / 94) */
+    float cie_y_integral;       /* SPD::cie_y_integral() spd.cpp:111-114 */
 } vmk_scene;
 
 /* ---- camera / film / integrator ---------------------------------------------------------------------- */

@@ -32,6 +32,8 @@ typedef struct vmk_host_options {
     const char *lut_path;       /* albedo-table blob (vision_amd/data/luts.bin); NULL = default next to the library */
     uint32_t mediums;           /* 0: ignore the scene's "mediums" block (the non-fog variant, BASELINE config 3);
                                  * 1: honour it (mediums.process, global medium, per-shape inside/outside, sensor medium) */
+    uint32_t spectrum;          /* 0: keep the scene's "spectrum" block; 1: force spectrum/srgb; 2: force spectrum/hero (the shipped
+                                 * scenes carry the hero line commented out — this flips it without editing the file) */
 } vmk_host_options;
 
 /* Register decoded pixels for an image file so the loader does not need a decoder for it.  `path` is matched
@@ -54,6 +56,12 @@ uint32_t vmk_host_output_spp(const vmk_host_scene *scene);    /* output.spp (nod
 const char *vmk_host_output_fn(const vmk_host_scene *scene);  /* output.fn */
 /* one line per plugin object the scene instantiated: "category/type name" (Vision's plugin namespace) */
 const char *vmk_host_describe(const vmk_host_scene *scene);
+
+/* Regenerate the sRGB -> sigmoid-spectrum coefficient table the hero spectrum uplifts colours with
+ * (sRGBToSpectrumTable_Data, hero.cpp:52-76; its header "srgb2spec.h" is not part of the reference checkout) from the CIE
+ * tables in `spectra_path` (vision_amd/data/spectra.bin) and write it to `out_path` (vision_amd/data/srgb2spec.bin, which
+ * vmk_host_load_scene reads for spectrum/hero scenes).  threads = 0: all cores.  See csrc/host/rgb2spec_opt.h. */
+int vmk_host_build_rgb2spec(const char *spectra_path, const char *out_path, uint32_t threads);
 
 const char *vmk_host_last_error(void);
 

@@ -131,6 +131,12 @@ inline float log_(float x) { // Cephes logf for normal x > 0 (callers pass 1 - u
     r += 0.693359375f * fe;
     return r;
 }
+// hero spectrum helpers (render_core/spectrum/hero.cpp): explicit fused multiply-add where the reference writes fma(),
+// rsqrt / atanh / cosh through the kernels above (ocarina's device intrinsics are unpinned)
+inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+inline float rsqrt_(float x) { return 1.f / sqrtf(x); }
+inline float atanh_(float x) { return 0.5f * log_((1.f + x) / (1.f - x)); }
+inline float cosh_(float x) { return 0.5f * (exp_(x) + exp_(-x)); }
 
 // ---- vectors ----
 struct float2 { float x, y; };

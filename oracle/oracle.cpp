@@ -164,6 +164,121 @@ inline float eval_slot1(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
 }
 
 // =====================================================================================================
+// a2. spectrum — render_core/spectrum/{srgb,hero}.cpp, base/color/{spd,spectrum}.cpp.
+// A dimension-3 SampledSpectrum is a float3 in both modes.  In hero mode the path's SampledWavelengths live in a
+// thread-local (set by Li for the path being traced); every decode below reads them.
+// =====================================================================================================
+struct Swl { float lambda[3]; float pdf[3]; };
+static thread_local Swl *tl_swl = nullptr; // non-null only while a hero-spectrum path is traced
+inline bool is_hero(const vmk_scene *s) { return s->spectrum == VMK_SPECTRUM_HERO; }
+inline float sample_visible_wavelength(float u) { return 538.f - 138.888889f * atanh_(0.85691062f - 1.82750197f * u); } // hero.cpp:15-18
+inline float visible_wavelength_PDF(float lambda) { return 0.0039398042f / sqr(cosh_(0.0072f * (lambda - 538.f))); }     // hero.cpp:21-24
+inline Swl sample_wavelengths(Sampler &sampler) { // hero.cpp:286-299, 1 draw
+    Swl swl;
+    float u = sampler.next_1d();
+    for (uint32_t i = 0; i < 3u; ++i) {
+        float offset = (float) i * (1.f / 3.f);
+        float up = fract_(u + offset);
+        swl.lambda[i] = sample_visible_wavelength(up);
+        swl.pdf[i] = visible_wavelength_PDF(swl.lambda[i]);
+    }
+    return swl;
+}
+inline float spd_eval(const float *f, float interval, float lambda) { // SPD::eval spd.cpp:79-86
+    float t = (clamp_(lambda, 360.f, 830.f) - 360.f) / interval;
+    uint32_t sample_count = (uint32_t) ((830.f - 360.f) / interval) + 1u;
+    uint32_t i = (uint32_t) fmin_(t, (float) (sample_count - 2u));
+    float l = f[i], r = f[i + 1u];
+    return lerp_(fract_(t), l, r);
+}
+inline float3 spd_eval3(const float *f, float interval, const Swl &swl) { return {spd_eval(f, interval, swl.lambda[0]), spd_eval(f, interval, swl.lambda[1]), spd_eval(f, interval, swl.lambda[2])}; }
+inline float sigmoid_polynomial(float3 c, float lambda) { // RGBSigmoidPolynomial hero.cpp:27-49
+    float x = fma_(fma_(c.x, lambda, c.y), lambda, c.z);
+    float v = 0.5f * fma_(x, rsqrt_(fma_(x, x, 1.f)), 1.f);
+    return isinf_(x) ? (x > 0.0f ? 1.f : 0.f) : v;
+}
+inline float inverse_smooth_step(float x) { return 0.5f - sin_(asin_(1.0f - 2.0f * x) * (1.0f / 3.0f)); } // hero.cpp:66-68
+inline float3 rgb2spec_fetch(const float *table, uint32_t maxc, float cx, float cy, float cz) { // tex3D, trilinear, clamp (App. B)
+    const int N = (int) VMK_RGB2SPEC_RES;
+    const float *t = table + (size_t) maxc * N * N * N * 4;
+    float x = cx * (float) N - 0.5f, y = cy * (float) N - 0.5f, z = cz * (float) N - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
+    float tx = x - fx0, ty = y - fy0, tz = z - fz0;
+    int x0 = clampi((int) fx0, 0, N - 1), x1 = clampi((int) fx0 + 1, 0, N - 1);
+    int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
+    int z0 = clampi((int) fz0, 0, N - 1), z1 = clampi((int) fz0 + 1, 0, N - 1);
+    auto at = [&](int xi, int yi, int zi) { const float *v = t + (((size_t) zi * N + yi) * N + xi) * 4; return make_float3(v[0], v[1], v[2]); };
+    float3 a = lerp3(ty, lerp3(tx, at(x0, y0, z0), at(x1, y0, z0)), lerp3(tx, at(x0, y1, z0), at(x1, y1, z0)));
+    float3 b = lerp3(ty, lerp3(tx, at(x0, y0, z1), at(x1, y0, z1)), lerp3(tx, at(x0, y1, z1), at(x1, y1, z1)));
+    return lerp3(tz, a, b);
+}
+inline float3 rgb2spec_albedo_coeffs(const vmk_scene *s, float3 rgb_in) { // RGBToSpectrumTable::decode_albedo, device variant hero.cpp:142-171
+    float3 rgb = {clamp_(rgb_in.x, 0.f, 1.f), clamp_(rgb_in.y, 0.f, 1.f), clamp_(rgb_in.z, 0.f, 1.f)};
+    float3 c = {0.0f, 0.0f, (rgb.x - 0.5f) * rsqrt_(rgb.x * (1.0f - rgb.x))};
+    if (!(rgb.x == rgb.y && rgb.y == rgb.z)) {
+        uint32_t maxc = rgb.x > rgb.y ? (rgb.x > rgb.z ? 0u : 2u) : (rgb.y > rgb.z ? 1u : 2u);
+        float v[3] = {rgb.x, rgb.y, rgb.z};
+        float z = v[maxc];
+        float x = v[(maxc + 1u) % 3u] / z;
+        float y = v[(maxc + 2u) % 3u] / z;
+        float zz = inverse_smooth_step(inverse_smooth_step(z));
+        const float res = (float) VMK_RGB2SPEC_RES;
+        const float sc = (res - 1.0f) / res, of = 0.5f / res;
+        c = rgb2spec_fetch(s->rgb2spec, maxc, fma_(x, sc, of), fma_(y, sc, of), fma_(zz, sc, of));
+    }
+    return c;
+}
+inline float3 rgb2spec_unbound_coeffs(const vmk_scene *s, float3 rgb_in, float *scale_out) { // decode_unbound hero.cpp:173-179
+    float3 rgb = {fmax_(rgb_in.x, 0.f), fmax_(rgb_in.y, 0.f), fmax_(rgb_in.z, 0.f)};
+    float m = fmax_(fmax_(rgb.x, rgb.y), rgb.z);
+    float scale = 2.f * m;
+    *scale_out = scale;
+    return rgb2spec_albedo_coeffs(s, scale == 0.f ? make_float3(0.f) : rgb / scale);
+}
+inline float3 sigmoid3(float3 c, const Swl &swl) { return {sigmoid_polynomial(c, swl.lambda[0]), sigmoid_polynomial(c, swl.lambda[1]), sigmoid_polynomial(c, swl.lambda[2])}; }
+// decode_to_albedo / decode_to_unbound_spectrum / decode_to_illumination (srgb.cpp:49-57, hero.cpp:331-342)
+inline float3 spec_albedo(const vmk_scene *s, float3 rgb) {
+    if (!is_hero(s)) return rgb;
+    return sigmoid3(rgb2spec_albedo_coeffs(s, rgb), *tl_swl);
+}
+inline float3 spec_unbound(const vmk_scene *s, float3 rgb) {
+    if (!is_hero(s)) return rgb;
+    float scale; float3 c = rgb2spec_unbound_coeffs(s, rgb, &scale);
+    return sigmoid3(c, *tl_swl) * scale; // RGBUnboundSpectrum::eval hero.cpp:201-203
+}
+inline float3 spec_illumination(const vmk_scene *s, float3 rgb) {
+    if (!is_hero(s)) return rgb;
+    float scale; float3 c = rgb2spec_unbound_coeffs(s, rgb, &scale);
+    return (sigmoid3(c, *tl_swl) * scale) * spd_eval3(s->spd_data + s->spd_cie[3], s->spd_cie_interval, *tl_swl); // hero.cpp:219-221
+}
+// Spectrum::linear_srgb (srgb.cpp:46-48; hero.cpp:265-267,281-291 + cie::xyz_to_linear_srgb cie.h:413-420)
+inline float3 spec_linear_srgb(const vmk_scene *s, float3 sp) {
+    if (!is_hero(s)) return sp;
+    const Swl &swl = *tl_swl;
+    const float *X = s->spd_data + s->spd_cie[0], *Y = s->spd_data + s->spd_cie[1], *Z = s->spd_data + s->spd_cie[2];
+    float v[3] = {sp.x, sp.y, sp.z};
+    float3 sum = make_float3(0.f);
+    uint32_t valid = 0;
+    for (int i = 0; i < 3; ++i) {
+        float p = swl.pdf[i];
+        float x = spd_eval(X, s->spd_cie_interval, swl.lambda[i]) * v[i], y = spd_eval(Y, s->spd_cie_interval, swl.lambda[i]) * v[i], z = spd_eval(Z, s->spd_cie_interval, swl.lambda[i]) * v[i];
+        sum = sum + make_float3(p == 0.f ? 0.f : x / p, p == 0.f ? 0.f : y / p, p == 0.f ? 0.f : z / p);
+        valid += p > 0.f ? 1u : 0u;
+    }
+    float factor = 1.f / ((float) valid * s->cie_y_integral);
+    float3 xyz = sum * factor;
+    return {3.240479f * xyz.x + -1.537150f * xyz.y + -0.498535f * xyz.z,
+            -0.969256f * xyz.x + 1.875991f * xyz.y + 0.041556f * xyz.z,
+            0.055648f * xyz.x + -0.204043f * xyz.y + 1.057311f * xyz.z};
+}
+inline float3 eval_slot_albedo(const vmk_scene *s, const vmk_slot &sl, float2 uv) { return spec_albedo(s, eval_slot3(s, sl, uv)); }             // shader_node.cpp:317-321
+inline float3 eval_slot_illumination(const vmk_scene *s, const vmk_slot &sl, float2 uv) { return spec_illumination(s, eval_slot3(s, sl, uv)); } // shader_node.cpp:329-333
+inline float3 eval_slot_spd(const vmk_scene *s, const vmk_slot &sl, float2 uv) { // number slot that may be an "spd" node (spd.cpp:36-39)
+    if (sl.tex == VMK_SLOT_SPD) return spd_eval3(s->spd_data + f2u(sl.v[0]), sl.v[2], *tl_swl);
+    return eval_slot3(s, sl, uv);
+}
+
+// =====================================================================================================
 // a4. ray / triangle / BVH — Geometry::trace_closest / trace_occlusion (geometry.cpp:168-185)
 // The reference delegates to OptiX; the restatement is a Moeller-Trumbore test with the hit-selection rule
 // "smallest t wins, ties resolved towards the smaller (inst, prim)", valid hits 0 < t < t_max.
@@ -532,10 +647,14 @@ struct Fresnel {
     float3 a{1, 1, 1}; // conductor eta | schlick F0 | F82 F0
     float3 b{0, 0, 0}; // conductor k   | F82 B
     float eta{1.f};    // dielectric / schlick eta[0]
+    bool eta_sp{false}; // hero: FresnelDielectric over an "spd" ior — a = the per-wavelength eta, eta = a.x (fresnel.h:83-91)
     float3 evaluate(float cos_t) const {
         switch (kind) {
             case FR_CONDUCTOR: return {fresnel_complex(cos_t, a.x, b.x), fresnel_complex(cos_t, a.y, b.y), fresnel_complex(cos_t, a.z, b.z)};
-            case FR_DIELECTRIC: { float f = fresnel_dielectric(cos_t, eta); return {f, f, f}; }
+            case FR_DIELECTRIC: {
+                if (eta_sp) return {fresnel_dielectric(cos_t, a.x), fresnel_dielectric(cos_t, a.y), fresnel_dielectric(cos_t, a.z)};
+                float f = fresnel_dielectric(cos_t, eta); return {f, f, f};
+            }
             case FR_SCHLICK: { // fresnel.h:60-67
                 float F_real = fresnel_dielectric(cos_t, eta);
                 float F0_real = schlick_F0_from_ior(eta);
@@ -869,7 +988,7 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
     l.frame = it.shading; // Material::compute_shading_frame without normal map (material.cpp:331-353)
     switch (m.type) {
         case VMK_MAT_DIFFUSE: { // diffuse.cpp:21-30
-            l.kr = eval_slot3(s, m.slot[0], it.uv);
+            l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
             if (m.flags & VMK_MATF_HAS_SIGMA) { // OrenNayar ctor bxdf.cpp:94-101
                 float sigma = eval_slot1(s, m.slot[1], it.uv);
                 sigma = sigma * PiOver2;
@@ -882,7 +1001,7 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
             break;
         }
         case VMK_MAT_MIRROR: { // mirror.cpp:60-74
-            l.kind = LB_MICROFACET; l.kr = eval_slot3(s, m.slot[0], it.uv);
+            l.kind = LB_MICROFACET; l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
             microfacet_alpha(s, m, 1, 2, it.uv, 0.0001f, &l.ax, &l.ay);
             l.fr.kind = FR_CONSTANT; l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
             break;
@@ -890,14 +1009,14 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
         case VMK_MAT_METAL: { // metal.cpp:137-156
             l.kind = LB_MICROFACET; l.kr = make_float3(1.f);
             microfacet_alpha(s, m, 2, 3, it.uv, 0.0001f, &l.ax, &l.ay);
-            l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot3(s, m.slot[0], it.uv); l.fr.b = eval_slot3(s, m.slot[1], it.uv);
+            l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot_spd(s, m.slot[0], it.uv); l.fr.b = eval_slot_spd(s, m.slot[1], it.uv);
             l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
             break;
         }
         case VMK_MAT_PLASTIC: { // plastic.cpp:103-122 (same double roughness_to_alpha as substrate)
             l.kind = LB_PLASTIC;
-            l.kr = eval_slot3(s, m.slot[0], it.uv);
-            float3 Rs = eval_slot3(s, m.slot[1], it.uv);
+            l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
+            float3 Rs = eval_slot_albedo(s, m.slot[1], it.uv);
             float ior = eval_slot1(s, m.slot[2], it.uv);
             float ax, ay; microfacet_alpha(s, m, 3, 4, it.uv, 0.0001f, &ax, &ay);
             if (m.flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
@@ -907,16 +1026,23 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
             break;
         }
         case VMK_MAT_METALLIC: { // metallic.cpp:42-60: MetallicLobe = PureReflectionLobe with compensation, F82-tint Fresnel
-            l.kind = LB_MICROFACET; l.kr = eval_slot3(s, m.slot[0], it.uv);
+            l.kind = LB_MICROFACET; l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
             microfacet_alpha(s, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay);
-            l.fr.kind = FR_F82; l.fr.a = l.kr; f82_init(l.fr, eval_slot3(s, m.slot[1], it.uv));
+            l.fr.kind = FR_F82; l.fr.a = l.kr; f82_init(l.fr, eval_slot_albedo(s, m.slot[1], it.uv));
             l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
             break;
         }
         case VMK_MAT_GLASS: { // glass.cpp:240-257
-            l.kind = LB_DIELECTRIC; l.kr = eval_slot3(s, m.slot[0], it.uv);
-            float ior = eval_slot1(s, m.slot[1], it.uv);
+            l.kind = LB_DIELECTRIC; l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
             float cos_t = dot(it.wo, it.ng); // Interaction::correct_eta interaction.cpp:80-83
+            if (m.slot[1].tex == VMK_SLOT_SPD) { // hero, dispersive: one ior per wavelength, directions follow eta[0] (lobe.cpp:353,383,407)
+                float3 iors = eval_slot_spd(s, m.slot[1], it.uv);
+                iors = cos_t > 0.f ? iors : make_float3(rcp(iors.x), rcp(iors.y), rcp(iors.z));
+                microfacet_alpha(s, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay);
+                l.fr.kind = FR_DIELECTRIC; l.fr.eta = iors.x; l.fr.a = iors; l.fr.eta_sp = true;
+                break;
+            }
+            float ior = eval_slot1(s, m.slot[1], it.uv);
             ior = cos_t > 0.f ? ior : rcp(ior);
             microfacet_alpha(s, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay);
             l.fr.kind = FR_DIELECTRIC; l.fr.eta = ior;
@@ -924,7 +1050,7 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
         }
         case VMK_MAT_SUBSTRATE: { // substrate.cpp:126-149
             l.kind = LB_FRESNEL_BLEND;
-            l.kr = eval_slot3(s, m.slot[0], it.uv); l.rs = eval_slot3(s, m.slot[1], it.uv);
+            l.kr = eval_slot_albedo(s, m.slot[0], it.uv); l.rs = eval_slot_albedo(s, m.slot[1], it.uv);
             float ax, ay; microfacet_alpha(s, m, 2, 3, it.uv, 0.0001f, &ax, &ay);
             if (m.flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
             l.ax = clamp_(ax, 0.0001f, 1.f); l.ay = clamp_(ay, 0.0001f, 1.f);
@@ -937,11 +1063,11 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
 inline void build_principled(const vmk_scene *s, const vmk_material &m, const Interaction &it, LobeSet &out) { // principled_bsdf.cpp:352-461
     out.is_set = true; out.n = 0;
     float2 uv = it.uv;
-    float3 color = eval_slot3(s, m.slot[VMK_P_COLOR], uv);
+    float3 color = eval_slot_albedo(s, m.slot[VMK_P_COLOR], uv);
     float ior = eval_slot1(s, m.slot[VMK_P_IOR], uv);
     float roughness = clamp_(eval_slot1(s, m.slot[VMK_P_ROUGHNESS], uv), 0.0001f, 1.f);
     float anisotropic = eval_slot1(s, m.slot[VMK_P_ANISOTROPIC], uv);
-    float3 specular_tint = eval_slot3(s, m.slot[VMK_P_SPEC_TINT], uv);
+    float3 specular_tint = eval_slot_albedo(s, m.slot[VMK_P_SPEC_TINT], uv);
     float aspect = sqrtf(1.f - anisotropic * 0.9f);
     float ax = fmax_(0.001f, sqr(roughness) / aspect), ay = fmax_(0.001f, sqr(roughness) * aspect);
     float3 weight = make_float3(1.f);
@@ -949,7 +1075,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
     float front_factor = cos_t > 0.f ? 1.f : 0.f;
     auto push = [&](const Lobe &l) { out.lobes[out.n++] = l; };
     if (s->luts.sheen_approx) { // sheen (Approximate mode default, principled_bsdf.cpp:260)
-        float3 sheen_tint = eval_slot3(s, m.slot[VMK_P_SHEEN_TINT], uv);
+        float3 sheen_tint = eval_slot_albedo(s, m.slot[VMK_P_SHEEN_TINT], uv);
         float sheen_weight = eval_slot1(s, m.slot[VMK_P_SHEEN_WEIGHT], uv) * front_factor;
         float sheen_roughness = eval_slot1(s, m.slot[VMK_P_SHEEN_ROUGHNESS], uv);
         Lobe l; l.kind = LB_SHEEN; l.frame = it.shading;
@@ -967,7 +1093,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
         float cc_roughness = clamp_(eval_slot1(s, m.slot[VMK_P_COAT_ROUGHNESS], uv), 0.0001f, 1.f);
         cc_roughness = sqr(cc_roughness);
         float cc_ior = eval_slot1(s, m.slot[VMK_P_COAT_IOR], uv);
-        float3 cc_tint = eval_slot3(s, m.slot[VMK_P_COAT_TINT], uv);
+        float3 cc_tint = eval_slot_albedo(s, m.slot[VMK_P_COAT_TINT], uv);
         Lobe l; l.kind = LB_MICROFACET; l.frame = it.shading; l.ax = l.ay = cc_roughness;
         l.fr.kind = FR_DIELECTRIC; l.fr.eta = cc_ior;
         l.kr = (weight * cc_weight) * cc_tint;
@@ -1118,7 +1244,7 @@ inline void light_select(const LightCtx &c, float u, uint32_t *index, float *pmf
     *pmf = light_pmf_inner(c, *index);
 }
 inline float3 area_L(const vmk_scene *s, const vmk_light &l, float2 uv, float3 ng, float3 w) { // area.cpp:91-95
-    float3 radiance = eval_slot3(s, l.color, uv) * l.scale;
+    float3 radiance = eval_slot_illumination(s, l.color, uv) * l.scale;
     return radiance * ((dot(w, ng) > 0.f || l.two_sided) ? 1.f : 0.f);
 }
 inline float area_PDF_wi(float pdf_pos, float3 ng, float3 w) { // area.cpp:114-118
@@ -1144,7 +1270,7 @@ inline LightSample area_sample_wi(const LightCtx &c, const vmk_light &l, const L
 }
 inline float3 env_L(const vmk_scene *s, const vmk_light &l, float3 local_dir) { // spherical.cpp:60-68
     float2 uv = {spherical_phi(local_dir) * Inv2Pi, spherical_theta(local_dir) * InvPi};
-    return eval_slot3(s, l.color, uv) * l.scale;
+    return eval_slot_illumination(s, l.color, uv) * l.scale;
 }
 inline float env_func_at(const vmk_scene *s, const vmk_light &l, uint32_t iu, uint32_t iv) { return s->alias_func[l.cond_offset + iv * l.res_x + iu]; }
 inline float env_map_PDF(const vmk_scene *s, const vmk_light &l, float2 p) { // alias2d.cpp:102-106
@@ -1195,7 +1321,7 @@ inline LightSample point_sample_wi(const vmk_scene *s, const vmk_light &l, const
     LightSample ls;
     float3 pos = ld3(l.position);
     float3 w_un = p_ref.pos - pos;
-    float3 value = eval_slot3(s, l.color, make_float2(0.f, 0.f)) * l.scale;
+    float3 value = eval_slot_illumination(s, l.color, make_float2(0.f, 0.f)) * l.scale;
     if (l.type == VMK_LIGHT_SPOT) {
         float3 w = normalize(w_un);
         float cos_theta = clamp_(dot(ld3(l.direction), w), l.cos_angle, l.cos_falloff_start);
@@ -1340,14 +1466,15 @@ inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const flo
 // §8f-1. Homogeneous medium + Henyey-Greenstein phase function — render_core/medium/homogeneous.cpp:30-70,
 //        base/scattering/interaction.h:136-139, interaction.cpp:12-32,114-134, geometry.cpp:187-199
 // =====================================================================================================
-inline float3 medium_sigma_t(const vmk_medium &m) { return (ld3(m.sigma_a) + ld3(m.sigma_s)) * m.scale; } // homogeneous.cpp:30
-inline float3 medium_sigma_s(const vmk_medium &m) { return ld3(m.sigma_s) * m.scale; }                    // :31
+// sigma_t / sigma_s as spectra: decode_to_unbound_spectrum of the RGB coefficients (homogeneous.cpp:30-31,34,54-55)
+inline float3 medium_sigma_t(const vmk_scene *s, const vmk_medium &m) { return spec_unbound(s, (ld3(m.sigma_a) + ld3(m.sigma_s)) * m.scale); }
+inline float3 medium_sigma_s(const vmk_scene *s, const vmk_medium &m) { return spec_unbound(s, ld3(m.sigma_s) * m.scale); }
 inline float3 exp3(float3 v) { return make_float3(exp_(v.x), exp_(v.y), exp_(v.z)); }
-inline float3 medium_Tr(const vmk_medium &m, float t) { return exp3((-1.f * medium_sigma_t(m)) * fmin_(RayTMax, t)); } // :33-36
-inline float3 medium_Tr_ray(const vmk_medium &m, const Ray &r) { return medium_Tr(m, length(r.d) * r.t_max); }        // :45-48
+inline float3 medium_Tr(const vmk_scene *s, const vmk_medium &m, float t) { return exp3((-1.f * medium_sigma_t(s, m)) * fmin_(RayTMax, t)); } // :33-36
+inline float3 medium_Tr_ray(const vmk_scene *s, const vmk_medium &m, const Ray &r) { return medium_Tr(s, m, length(r.d) * r.t_max); }        // :45-48
 // Geometry::Tr geometry.cpp:187-199
 inline float3 geometry_Tr(const vmk_scene *s, const vmk_render_params &p, const Ray &r, uint32_t medium) {
-    if (p.process_mediums && medium != VMK_INVALID) return medium_Tr_ray(s->mediums[medium], r);
+    if (p.process_mediums && medium != VMK_INVALID) return medium_Tr_ray(s, s->mediums[medium], r);
     return make_float3(1.f);
 }
 // the medium a ray spawned at `it` towards dir travels in — Interaction::spawn_ray_state interaction.cpp:114-123
@@ -1360,8 +1487,8 @@ inline float phase_HG(float cos_theta, float g) { // interaction.h:136-139
     return Inv4Pi * (1.f - sqr(g)) / (denom * sqrtf(denom));
 }
 // HomogeneousMedium::sample homogeneous.cpp:50-70 (2 draws); may replace `it` by a medium interaction
-inline float3 medium_sample(const vmk_medium &m, uint32_t medium_id, const Ray &ray, Interaction &it, Sampler &sampler) {
-    float3 sigma_t = medium_sigma_t(m), sigma_s = medium_sigma_s(m);
+inline float3 medium_sample(const vmk_scene *s, const vmk_medium &m, uint32_t medium_id, const Ray &ray, Interaction &it, Sampler &sampler) {
+    float3 sigma_t = medium_sigma_t(s, m), sigma_s = medium_sigma_s(s, m);
     uint32_t channel = (uint32_t) (sampler.next_1d() * 3.f); if (channel > 2u) channel = 2u;
     float st_c = channel == 0 ? sigma_t.x : (channel == 1 ? sigma_t.y : sigma_t.z);
     float dist = -log_(1.f - sampler.next_1d()) / st_c;
@@ -1375,7 +1502,7 @@ inline float3 medium_sample(const vmk_medium &m, uint32_t medium_id, const Ray &
         mi.med_inside = medium_id; mi.med_outside = medium_id;
         it = mi;
     }
-    float3 tr = medium_Tr(m, t);
+    float3 tr = medium_Tr(s, m, t);
     float3 density = sampled_medium ? sigma_t * tr : tr;
     float pdf = (density.x + density.y + density.z) / 3.f;
     return sampled_medium ? tr * sigma_s / pdf : tr / pdf;
@@ -1402,9 +1529,12 @@ inline float3 hg_sample(float3 wo, float g, Sampler &sampler, float *f_out) {
 // =====================================================================================================
 struct PathStats { uint32_t closest{0}, shadow{0}, hits{0}; };
 
-inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sampler, float *dbg = nullptr) {
+// `swl`: the path's SampledWavelengths (RenderEnv::initial integrator.cpp:48-57), hero spectrum only.  L is linear sRGB
+// (every contribution goes through Spectrum::linear_srgb when it is added), T a spectrum.
+inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sampler, float *dbg = nullptr, Swl *swl = nullptr) {
     int vtx = 0;
     const vmk_scene *s = sv.s;
+    tl_swl = swl;
     LightCtx lc{s, &p};
     float3 L = make_float3(0.f), T = make_float3(1.f);
     float scatter_pdf = 1e16f;
@@ -1426,13 +1556,13 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
                 LightSampleContext p_ref{ray.o, prev_surface_ng};
                 LightEval eval = light_evaluate_miss_wi(lc, p_ref, ray.d);
                 float weight = correct_bsdf_weight(MIS_weight(scatter_pdf, eval.pdf), bounces);
-                L += (eval.L * 1.f * weight) * T;
+                L += spec_linear_srgb(s, (eval.L * 1.f * weight) * T);
             }
             break;
         }
         Interaction it = compute_surface_interaction(s, hit, ray);
         if (p.process_mediums && ray_medium != VMK_INVALID) // integrator.cpp:199-206
-            T *= medium_sample(s->mediums[ray_medium], ray_medium, ray, it, sampler);
+            T *= medium_sample(s, s->mediums[ray_medium], ray_medium, ray, it, sampler);
         if (!it.has_material() && !it.has_phase()) { // integrator.cpp:208-214
             ray_medium = spawn_medium(p, it, ray.d);
             ray = spawn_ray(it.pos, it.ng, ray.d);
@@ -1445,7 +1575,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
             LightEval eval = light_evaluate_hit_wi(lc, p_ref, it);
             float3 tr = geometry_Tr(s, p, ray, ray_medium);
             float weight = correct_bsdf_weight(MIS_weight(scatter_pdf, eval.pdf), bounces);
-            L += eval.L * T * weight * tr;
+            L += spec_linear_srgb(s, eval.L * T * weight * tr);
         }
         prev_surface_ng = it.ng;
         // NEE
@@ -1467,6 +1597,8 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         } else {
             LobeSet lobes;
             build_lobe_set(s, s->materials[it.mat_id], it, lobes);
+            // SampledWavelengths::check_dispersive (spectrum.cpp:32-39, integrator.cpp:264): a dispersive lobe keeps the hero wavelength only
+            if (swl && s->materials[it.mat_id].type == VMK_MAT_GLASS && (s->materials[it.mat_id].flags & VMK_MATF_DISPERSIVE)) { swl->pdf[1] = 0.f; swl->pdf[2] = 0.f; }
             scatter_eval = evaluator_evaluate(s, lobes, it.ng, it.wo, wi);
             bs = evaluator_sample(s, lobes, it.ng, it.wo, sampler);
         }
@@ -1478,7 +1610,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         float3 Ld = make_float3(0.f);
         if (!occluded && scatter_eval.valid() && ls.valid()) Ld = ls.eval.L * scatter_eval.f * weight / ls.eval.pdf;
         if (p.mis_mode == 2) Ld = Ld * 0.f;
-        L += T * Ld * tr;
+        L += spec_linear_srgb(s, T * Ld * tr);
         eta_scale *= sqr(bs.eta);
         float lum = max_comp(T);
         if (!bs.valid() || lum == 0.f) break;
@@ -1494,6 +1626,15 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         ray = spawn_ray(it.pos, it.ng, bs.wi);
     }
     return L;
+}
+
+// RenderEnv::initial (integrator.cpp:48-57): sampler->temporary { start(pixel, frame, -1); sample_wavelength } — its own
+// sampler state, 1 draw; null for the srgb spectrum
+inline Swl *path_wavelengths(const vmk_scene *s, uint32_t x, uint32_t y, uint32_t frame, Swl &storage) {
+    if (!is_hero(s)) return nullptr;
+    Sampler tmp; tmp.start(x, y, frame, 0xFFFFFFFFu);
+    storage = sample_wavelengths(tmp);
+    return &storage;
 }
 
 inline uint32_t bitrev(uint32_t v, uint32_t bits) { uint32_t r = 0; for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | ((v >> i) & 1u); } return r; }
@@ -1545,7 +1686,8 @@ int orc_render(void *h, const vmk_render_params *p, uint32_t frame_begin, uint32
                     Ray ray = generate_ray(*p, x, y, sampler);
                     sampler.start(x, y, f, 1); // path_tracing kernel, integrator.cpp:93
                     tl_cnt.paths++;
-                    float3 L = Li(sv, *p, ray, sampler);
+                    Swl swl_store; Swl *swl = path_wavelengths(sv.s, x, y, f, swl_store);
+                    float3 L = Li(sv, *p, ray, sampler, nullptr, swl);
                     float a = 1.f / (float) (f + 1u);
                     float4 val = {L.x, L.y, L.z, 1.f};
                     acc = lerp4(a, acc, val);
@@ -1581,7 +1723,8 @@ uint32_t orc_dump_rays(void *h, const vmk_render_params *p, uint32_t frame, uint
             Ray ray = generate_ray(*p, x, y, sampler);
             sampler.start(x, y, frame, 1);
             dump.seq = 0;
-            Li(sv, *p, ray, sampler);
+            Swl swl_store; Swl *swl = path_wavelengths(sv.s, x, y, frame, swl_store);
+            Li(sv, *p, ray, sampler, nullptr, swl);
             dump.path++;
         }
     tl_dump = nullptr;
@@ -1713,8 +1856,27 @@ int orc_test_eval(void *h, const vmk_render_params *p, uint32_t kind, uint32_t n
                 Ray r = generate_ray(*p, px, py, s);
                 s.start(px, py, frame, 1);
                 for (int k = 0; k < 64; ++k) o[k] = 0.f;
-                float3 L = Li(*sv, *p, r, s, o);
+                Swl swl_store; Swl *swl = path_wavelengths(sv->s, px, py, frame, swl_store);
+                float3 L = Li(*sv, *p, r, s, o, swl);
                 o[64] = L.x; o[65] = L.y; o[66] = L.z;
+                break;
+            }
+            case 60: { // oracle-only, hero scenes: in (r, g, b, u) -> lambda[3], pdf[3], albedo / unbound / illumination spectra, linear_srgb of each
+                if (!sv || !is_hero(sv->s)) return -1;
+                Sampler smp; smp.state = 0;
+                Swl swl;
+                for (uint32_t k = 0; k < 3u; ++k) { // sample_wavelength with the draw replaced by the given u (hero.cpp:286-299)
+                    float up = fract_(a[3] + (float) k * (1.f / 3.f));
+                    swl.lambda[k] = sample_visible_wavelength(up); swl.pdf[k] = visible_wavelength_PDF(swl.lambda[k]);
+                }
+                tl_swl = &swl;
+                float3 rgb = make_float3(a[0], a[1], a[2]);
+                float3 al = spec_albedo(sv->s, rgb), un = spec_unbound(sv->s, rgb), il = spec_illumination(sv->s, rgb);
+                float3 ral = spec_linear_srgb(sv->s, al), run = spec_linear_srgb(sv->s, un), ril = spec_linear_srgb(sv->s, il);
+                float v[24] = {swl.lambda[0], swl.lambda[1], swl.lambda[2], swl.pdf[0], swl.pdf[1], swl.pdf[2], al.x, al.y, al.z, un.x, un.y, un.z,
+                               il.x, il.y, il.z, ral.x, ral.y, ral.z, run.x, run.y, run.z, ril.x, ril.y, ril.z};
+                for (int k = 0; k < 24; ++k) o[k] = v[k];
+                tl_swl = nullptr;
                 break;
             }
             case 50: { // oracle-only: refract (optics.h:28-39; src/tests/test_bxdf.cpp:28-40 vector), Fresnel helpers

@@ -16,10 +16,16 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          ("cbox_media", "scenes/cbox/cbox_media.json", 32, 32, 4), ("classroom_fog", "scenes/classroom/vision_scene.json", 48, 27, 2),
          ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4), ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),
          ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
-         ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4), ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4), ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4)]
-MEDIA = {"cbox_media", "classroom_fog"}  # rendered with the scene's "mediums" block honoured
+         ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4), ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4), ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4),
+         # spectrum/hero: every material family incl. dispersive BK7 glass + measured Cu, textures; diffuse only;
+         # media; point + spot lights; config 4 "spectral glass"; classroom with its environment map and textures
+         ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
+         ("cbox_hero_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("cbox_hero_lights", "scenes/cbox/cbox_hero_lights.json", 32, 32, 4),
+         ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2), ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2)]
+MEDIA = {"cbox_media", "classroom_fog", "cbox_hero_media"}  # rendered with the scene's "mediums" block honoured
+HERO = {"glass_of_water_hero", "classroom_hero"}           # shipped scenes with the spectrum forced to hero (vmk_host_options.spectrum)
 for name, path, w, h, spp in CASES:
-    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA)
+    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA, spectrum="hero" if name in HERO else None)
     img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
     out = os.path.join(ROOT, "tests", "golden", f"{name}_{w}x{h}x{spp}.npy")
     np.save(out, img)

@@ -105,10 +105,24 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4),           # lightsampler/power
     ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4),           # principled_bsdf sheen (LTC) layer
     ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4),           # material/metallic, material/add
+    # spectrum/hero (§8f-2): the vmk_hero.hip instance of the megakernel, all four <FULL, MEDIA> variants
+    ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4),             # every material family, dispersive BK7 glass, measured Cu, texture
+    ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4), # single-lobe variant
+    ("cbox_hero_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), # sigma_a / sigma_s uplifted as unbound spectra
+    ("cbox_hero_lights", "scenes/cbox/cbox_hero_lights.json", 32, 32, 4),  # point + spot illumination spectra
+    ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),  # config 4 as worded: "spectral glass"
+    ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2),            # environment map + image textures through the uplift
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
-    hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog"))
-    assert backend.self_check() == w * h  # the megakernel variant this scene selects agrees with the unit kernel (vmk_self_check)
+    hero = "hero" in name
+    hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog", "cbox_hero_media"),
+                          spectrum="hero" if name in ("glass_of_water_hero", "classroom_hero") else None)
+    assert (hs.scene.spectrum == 1) == hero
+    if hero:  # the unit kernels are the sRGB instance: asking for the self-check on a hero scene is an error, not a silent pass
+        with pytest.raises(Exception):
+            backend.self_check()
+    else:
+        assert backend.self_check() == w * h  # the megakernel variant this scene selects agrees with the unit kernel (vmk_self_check)
     backend.reset_accum(); backend.reset_counters()
     backend.render_batch(0, spp)
     img = backend.download_accum()

@@ -101,7 +101,8 @@ def test_json_comments_and_defaults(built, tmp_path):
 @pytest.mark.parametrize("mutate, needle", [
     (lambda s: s["materials"].append({"type": "subsurface", "name": "x", "param": {}}), "material type 'subsurface'"),
     (lambda s: s["integrator"].update(type="rt"), "integrator/rt"),
-    (lambda s: s["spectrum"].update(type="hero"), "spectrum/hero"),
+    (lambda s: s["spectrum"].update(type="hero", param={"dimension": 4}), "dimension != 3"),
+    (lambda s: s["spectrum"].update(type="rgb"), "spectrum/rgb"),
     (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "projector", "param": {}}), "light/projector"),
     (lambda s: s["camera"]["param"].update(filter={"type": "blackman", "param": {"radius": 1}}), "filter/blackman"),
     (lambda s: s["shapes"].append({"type": "sphere", "name": "s", "param": {}}), "shape/sphere"),
@@ -173,3 +174,47 @@ def test_power_light_sampler_table(built):
     assert sc.light_alias_integral == pytest.approx(sum(func) / len(func), rel=1e-6)
     uni = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_lights.json"), width=16, height=16)
     assert uni.params.light_sampler == 0 and uni.scene.light_alias_offset == _abi.INVALID
+
+
+def test_hero_spectrum_tables(built):
+    """spectrum/hero (hero.cpp:243-252): CIE tables as 94-sample SPDs, metal / dispersive-glass "spd" slots, uplift table."""
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_hero.json"), width=16, height=16)
+    sc = hs.scene
+    assert sc.spectrum == _abi.SPECTRUM_HERO and "spectrum/hero" in hs.description
+    assert sc.spd_cie_count == 94 and sc.spd_cie_interval == pytest.approx(471.0 / 94)   # spd.cpp:27-33,50-53
+    assert sc.cie_y_integral == pytest.approx(106.856895, rel=1e-5)                          # the CIE Y integral (spd.cpp:15-25)
+    y = np.array([sc.spd_data[sc.spd_cie[1] + i] for i in range(94)])
+    assert y.argmax() == 39 and y[39] == pytest.approx(1.0, abs=1e-3)                       # ybar peaks at 555 nm = sample 39
+    mats = {hs.description.split("\n")[1 + i].split()[-1]: sc.materials[i] for i in range(sc.n_materials)}
+    glass, metal = mats["ShortBox"], mats["TallBox"]
+    assert glass.flags & 4 and glass.slot[1].tex == _abi.SLOT_SPD                           # BK7: dispersive, tabulated ior
+    off, n = (np.array(list(glass.slot[1].v[:2]), np.float32).view(np.uint32))
+    assert n == 94 and 1.50 < sc.spd_data[off + 93] < sc.spd_data[off] < 1.54               # normal dispersion, SPD::to_list spd.h:41-47
+    assert metal.slot[0].tex == _abi.SLOT_SPD and metal.slot[1].tex == _abi.SLOT_SPD
+    off, n = (np.array(list(metal.slot[0].v[:2]), np.float32).view(np.uint32))
+    assert n == 95 and metal.slot[0].v[2] == pytest.approx(471.0 / 95)
+    # srgb scenes carry none of this
+    srgb = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_materials.json"), width=16, height=16)
+    assert srgb.scene.spectrum == _abi.SPECTRUM_SRGB and not srgb.scene.rgb2spec and srgb.scene.n_spd == 0
+
+
+def test_hero_uplift_round_trip(built):
+    """The regenerated sRGB->spectrum table (csrc/host/rgb2spec_opt.h; Vision's own table is absent from the checkout): the
+    uplifted spectrum of an sRGB colour, seen under D65 through the CIE observer, is that colour again.  Evaluated through
+    the oracle's decode + Monte-Carlo wavelength sampling (hero.cpp:286-299), i.e. the estimator a render uses."""
+    from oracle import oracle_py
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_hero.json"), width=16, height=16)
+    osc = oracle_py.OracleScene(hs)
+    u = ((np.arange(4096) + 0.5) / 4096).astype(np.float32)
+    for rgb in ([0.8, 0.2, 0.1], [0.2, 0.6, 0.9], [0.5, 0.5, 0.5], [0.05, 0.7, 0.05], [1.0, 1.0, 1.0]):
+        inp = np.concatenate([np.tile(np.array(rgb, np.float32), (len(u), 1)), u[:, None]], 1)
+        o = osc.test_eval(hs.params, 60, inp, 24)
+        assert np.all((o[:, 0:3] >= 360) & (o[:, 0:3] <= 830)) and np.all(o[:, 3:6] > 0)
+        assert np.all((o[:, 6:9] >= 0) & (o[:, 6:9] <= 1))                                  # albedo spectra stay in [0, 1]
+        back = o[:, 21:24].astype(np.float64).mean(0)                                       # illumination = uplift x D65
+        # 1.2e-2: the table is fitted on exact 5 nm tables, the renderer integrates against SPD::eval's 471/94 nm spacing (spd.cpp:50-53)
+        assert np.allclose(back, rgb, atol=1.2e-2), (rgb, back)
+    # unbound colours scale linearly: (3, 2, 0.5) = 6 x (0.5, 1/3, 1/12)
+    o6 = osc.test_eval(hs.params, 60, np.array([[3.0, 2.0, 0.5, 0.3]], np.float32), 24)[0]
+    o1 = osc.test_eval(hs.params, 60, np.array([[0.5, 1 / 3, 1 / 12, 0.3]], np.float32), 24)[0]
+    assert np.allclose(o6[9:12], 6 * o1[6:9], rtol=1e-5)

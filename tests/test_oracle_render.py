@@ -22,14 +22,21 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
          ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4),  # lightsampler/power over area + point + spot
          ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4),  # principled_bsdf with its sheen (LTC) layer
-         ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4)]  # material/metallic and material/add
-MEDIA = {"cbox_media", "classroom_fog"}
+         ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4),  # material/metallic and material/add
+         # spectrum/hero: all material families incl. dispersive BK7 + measured Cu; diffuse only; media; point + spot
+         # lights; config 4 as worded ("spectral glass"); classroom with its environment map and image textures
+         ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
+         ("cbox_hero_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("cbox_hero_lights", "scenes/cbox/cbox_hero_lights.json", 32, 32, 4),
+         ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2), ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2)]
+MEDIA = {"cbox_media", "classroom_fog", "cbox_hero_media"}
+HERO = {"glass_of_water_hero", "classroom_hero"}  # shipped scenes with the spectrum forced to hero (vmk_host_options.spectrum)
 
 
 @pytest.mark.parametrize("name, path, w, h, spp", CASES)
 def test_oracle_matches_committed_golden(built, name, path, w, h, spp):
-    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA)
+    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA, spectrum="hero" if name in HERO else None)
     assert bool(hs.params.process_mediums) == (name in MEDIA)
+    assert (hs.scene.spectrum == _abi.SPECTRUM_HERO) == ("hero" in name)
     img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
     gold = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_{w}x{h}x{spp}.npy"))
     assert np.array_equal(img.view(np.uint32), gold.view(np.uint32))  # deterministic: bit-exact across threads/runs

@@ -1,7 +1,10 @@
 """ctypes mirror of include/vmk.h and include/vmk_host.h (plain C structs, no torch types)."""
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+SLOT_SPD = 0xFFFFFFFD
+SPECTRUM_SRGB, SPECTRUM_HERO = 0, 1
+RGB2SPEC_RES = 64
 INVALID = 0xFFFFFFFF
 MAX_SLOTS = 18
 LUT_RES = 32
@@ -61,7 +64,9 @@ class Scene(C.Structure):
                 ("alias_prob", C.POINTER(f32)), ("alias_idx", C.POINTER(u32)), ("alias_func", C.POINTER(f32)),
                 ("env_light", u32), ("world_min", f32 * 3), ("world_max", f32 * 3), ("luts", Luts),
                 ("n_mediums", u32), ("mediums", C.POINTER(Medium)),
-                ("light_alias_offset", u32), ("light_alias_integral", f32)]
+                ("light_alias_offset", u32), ("light_alias_integral", f32),
+                ("spectrum", u32), ("rgb2spec", C.POINTER(f32)), ("spd_data", C.POINTER(f32)), ("n_spd", u32),
+                ("spd_cie", u32 * 4), ("spd_cie_count", u32), ("spd_cie_interval", f32), ("cie_y_integral", f32)]
 
 
 _T = FILTER_TABLE_SIZE
@@ -98,7 +103,7 @@ class AccelInfo(C.Structure):
 
 class HostOptions(C.Structure):
     _fields_ = [("width", u32), ("height", u32), ("max_depth", i32), ("min_depth", i32), ("procedural_env", u32),
-                ("drop_unsupported_lights", u32), ("lut_path", C.c_char_p), ("mediums", u32)]
+                ("drop_unsupported_lights", u32), ("lut_path", C.c_char_p), ("mediums", u32), ("spectrum", u32)]
 
 
 # every symbol include/vmk.h declares (checked by tests/test_abi.py without a GPU)
@@ -109,4 +114,4 @@ VMK_SYMBOLS = ["vmk_create", "vmk_destroy", "vmk_last_error", "vmk_abi_version",
                "vmk_precompute_albedo", "vmk_render_aov", "vmk_self_check"]
 HOST_SYMBOLS = ["vmk_host_register_image", "vmk_host_clear_images", "vmk_host_list_images", "vmk_host_load_scene",
                 "vmk_host_free_scene", "vmk_host_scene_tables", "vmk_host_render_params", "vmk_host_output_spp",
-                "vmk_host_output_fn", "vmk_host_describe", "vmk_host_last_error"]
+                "vmk_host_output_fn", "vmk_host_describe", "vmk_host_last_error", "vmk_host_build_rgb2spec"]

@@ -127,6 +127,13 @@ VD float log_(float x) { // Cephes logf for normal x > 0 (callers pass 1 - u wit
     r += 0.693359375f * fe;
     return r;
 }
+// hero spectrum helpers (render_core/spectrum/hero.cpp): explicit fused multiply-add where the reference writes fma(),
+// rsqrt / atanh / cosh through the kernels above (ocarina's device intrinsics are unpinned)
+VD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+VD float fract_(float x) { return x - floor_(x); }
+VD float rsqrt_(float x) { return 1.f / sqrt_(x); }
+VD float atanh_(float x) { return 0.5f * log_((1.f + x) / (1.f - x)); }
+VD float cosh_(float x) { return 0.5f * (exp_(x) + exp_(-x)); }
 constexpr float Inv4Pi = 0.07957747154594766788f;
 
 // ---- vectors ----

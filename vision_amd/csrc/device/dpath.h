@@ -3,6 +3,21 @@
 #pragma once
 #include "dscene.h"
 
+// VMK_HERO = 1 compiles the path code for the hero-wavelength spectrum (render_core/spectrum/hero.cpp) in its own
+// translation unit (vmk_hero.hip, namespace vmkd_hero): every colour that enters the path is uplifted to a spectrum
+// sampled at the path's three wavelengths.  With VMK_HERO = 0 (srgb.cpp) the colour helpers below are the identity and
+// the SWL_P / SWL_A parameter macros expand to nothing, so the sRGB megakernel is the same code as before.
+#ifndef VMK_HERO
+#define VMK_HERO 0
+#endif
+#if VMK_HERO
+#define SWL_P , const Swl &swl
+#define SWL_A , swl
+#else
+#define SWL_P
+#define SWL_A
+#endif
+
 namespace vmkd {
 
 // =====================================================================================================
@@ -143,6 +158,145 @@ VD V3 eval_slot3(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt) {
 VD float eval_slot1(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt) {
     if (sl.tex == VMK_INVALID) return sl.v[0];
     return eval_slot3(S, sl, uv, cnt).x;
+}
+
+// =====================================================================================================
+// a2. spectrum — render_core/spectrum/{srgb,hero}.cpp, base/color/{spd,spectrum}.cpp
+// A SampledSpectrum of dimension 3 is a V3 in both modes: the (R, G, B) channels for srgb, the values at the path's
+// wavelengths (hero, hero + 1/3, hero + 2/3 of the sampling domain) for hero.
+// =====================================================================================================
+#if VMK_HERO
+struct Swl { V3 lambda, pdf; }; // SampledWavelengths (spectrum.h:18-56): pdf == 0 marks an invalidated secondary wavelength
+VD float sample_visible_wavelength(float u) { return 538.f - 138.888889f * atanh_(0.85691062f - 1.82750197f * u); } // hero.cpp:15-18
+VD float visible_wavelength_PDF(float lambda) { return 0.0039398042f / sqr(cosh_(0.0072f * (lambda - 538.f))); }     // hero.cpp:21-24
+// HeroWavelengthSpectrum::sample_wavelength (hero.cpp:286-299), 1 draw
+VD Swl sample_wavelengths(Sampler &sampler) {
+    Swl swl;
+    float u = sampler.next_1d();
+    float l[3], p[3];
+#pragma unroll
+    for (uint32_t i = 0; i < 3u; ++i) {
+        float offset = (float) i * (1.f / 3.f);
+        float up = fract_(u + offset);
+        l[i] = sample_visible_wavelength(up);
+        p[i] = visible_wavelength_PDF(l[i]);
+    }
+    swl.lambda = {l[0], l[1], l[2]}; swl.pdf = {p[0], p[1], p[2]};
+    return swl;
+}
+// SPD::eval (spd.cpp:79-86)
+VD float spd_eval(const float *f, float interval, float lambda) {
+    float t = (clamp_(lambda, 360.f, 830.f) - 360.f) / interval;
+    uint32_t sample_count = (uint32_t) ((830.f - 360.f) / interval) + 1u;
+    uint32_t i = (uint32_t) fmin_(t, (float) (sample_count - 2u));
+    float l = f[i], r = f[i + 1u];
+    return lerp_(fract_(t), l, r);
+}
+VD V3 spd_eval3(const float *f, float interval, const Swl &swl) { return {spd_eval(f, interval, swl.lambda.x), spd_eval(f, interval, swl.lambda.y), spd_eval(f, interval, swl.lambda.z)}; }
+// RGBSigmoidPolynomial (hero.cpp:27-49)
+VD float sigmoid_polynomial(V3 c, float lambda) {
+    float x = fma_(fma_(c.x, lambda, c.y), lambda, c.z);
+    float s = 0.5f * fma_(x, rsqrt_(fma_(x, x, 1.f)), 1.f);
+    return isinf_(x) ? (x > 0.0f ? 1.f : 0.f) : s;
+}
+VD float inverse_smooth_step(float x) { return 0.5f - sin_(asin_(1.0f - 2.0f * x) * (1.0f / 3.0f)); } // hero.cpp:66-68
+// RGBToSpectrumTable::decode_albedo, device variant (hero.cpp:142-171): the three 64^3 float4 textures, trilinear,
+// clamp addressing, texel centres at (i + 0.5) / res.  Kept out of line: ~10 call sites in the material code.
+__device__ __noinline__ void rgb2spec_fetch_ool(const float *table, uint32_t maxc, float cx, float cy, float cz, V3 *out) {
+    const int N = (int) VMK_RGB2SPEC_RES;
+    const float4 *t = reinterpret_cast<const float4 *>(table) + (size_t) maxc * N * N * N;
+    float x = cx * (float) N - 0.5f, y = cy * (float) N - 0.5f, z = cz * (float) N - 0.5f;
+    float fx0 = floor_(x), fy0 = floor_(y), fz0 = floor_(z);
+    float tx = x - fx0, ty = y - fy0, tz = z - fz0;
+    int x0 = clampi((int) fx0, 0, N - 1), x1 = clampi((int) fx0 + 1, 0, N - 1);
+    int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
+    int z0 = clampi((int) fz0, 0, N - 1), z1 = clampi((int) fz0 + 1, 0, N - 1);
+    auto at = [&](int xi, int yi, int zi) { float4 v = t[((size_t) zi * N + yi) * N + xi]; return V3{v.x, v.y, v.z}; };
+    V3 a = lerp3(ty, lerp3(tx, at(x0, y0, z0), at(x1, y0, z0)), lerp3(tx, at(x0, y1, z0), at(x1, y1, z0)));
+    V3 b = lerp3(ty, lerp3(tx, at(x0, y0, z1), at(x1, y0, z1)), lerp3(tx, at(x0, y1, z1), at(x1, y1, z1)));
+    *out = lerp3(tz, a, b);
+}
+VD V3 rgb2spec_albedo_coeffs(const DScene &S, V3 rgb_in) {
+    V3 rgb = {clamp_(rgb_in.x, 0.f, 1.f), clamp_(rgb_in.y, 0.f, 1.f), clamp_(rgb_in.z, 0.f, 1.f)};
+    V3 c = {0.0f, 0.0f, (rgb.x - 0.5f) * rsqrt_(rgb.x * (1.0f - rgb.x))};
+    if (!(rgb.x == rgb.y && rgb.y == rgb.z)) {
+        uint32_t maxc = rgb.x > rgb.y ? (rgb.x > rgb.z ? 0u : 2u) : (rgb.y > rgb.z ? 1u : 2u);
+        float v[3] = {rgb.x, rgb.y, rgb.z};
+        float z = v[maxc];
+        float x = v[(maxc + 1u) % 3u] / z;
+        float y = v[(maxc + 2u) % 3u] / z;
+        float zz = inverse_smooth_step(inverse_smooth_step(z));
+        const float res = (float) VMK_RGB2SPEC_RES;
+        const float sc = (res - 1.0f) / res, of = 0.5f / res;
+        rgb2spec_fetch_ool(S.hero.rgb2spec, maxc, fma_(x, sc, of), fma_(y, sc, of), fma_(zz, sc, of), &c);
+    }
+    return c;
+}
+// decode_unbound (hero.cpp:173-179): (c0, c1, c2, scale)
+VD V3 rgb2spec_unbound_coeffs(const DScene &S, V3 rgb_in, float *scale_out) {
+    V3 rgb = {fmax_(rgb_in.x, 0.f), fmax_(rgb_in.y, 0.f), fmax_(rgb_in.z, 0.f)};
+    float m = max_comp(rgb);
+    float scale = 2.f * m;
+    *scale_out = scale;
+    return rgb2spec_albedo_coeffs(S, scale == 0.f ? mk3(0.f) : rgb / scale);
+}
+VD V3 sigmoid3(V3 c, const Swl &swl) { return {sigmoid_polynomial(c, swl.lambda.x), sigmoid_polynomial(c, swl.lambda.y), sigmoid_polynomial(c, swl.lambda.z)}; }
+#endif
+// decode_to_albedo / decode_to_unbound_spectrum / decode_to_illumination (srgb.cpp:49-57, hero.cpp:331-342)
+VD V3 spec_albedo(const DScene &S, V3 rgb SWL_P) {
+#if VMK_HERO
+    return sigmoid3(rgb2spec_albedo_coeffs(S, rgb), swl);
+#else
+    return rgb;
+#endif
+}
+VD V3 spec_unbound(const DScene &S, V3 rgb SWL_P) {
+#if VMK_HERO
+    float scale; V3 c = rgb2spec_unbound_coeffs(S, rgb, &scale);
+    return sigmoid3(c, swl) * scale; // RGBUnboundSpectrum::eval hero.cpp:201-203
+#else
+    return rgb;
+#endif
+}
+VD V3 spec_illumination(const DScene &S, V3 rgb SWL_P) {
+#if VMK_HERO
+    float scale; V3 c = rgb2spec_unbound_coeffs(S, rgb, &scale);
+    return (sigmoid3(c, swl) * scale) * spd_eval3(S.hero.spd_data + S.hero.spd_cie[3], S.hero.spd_cie_interval, swl); // RGBIlluminationSpectrum::eval hero.cpp:219-221
+#else
+    return rgb;
+#endif
+}
+// Spectrum::linear_srgb (srgb.cpp:46-48; hero.cpp:265-267,281-291 + cie::xyz_to_linear_srgb cie.h:413-420)
+VD V3 spec_linear_srgb(const DScene &S, V3 sp SWL_P) {
+#if VMK_HERO
+    const float *X = S.hero.spd_data + S.hero.spd_cie[0], *Y = S.hero.spd_data + S.hero.spd_cie[1], *Z = S.hero.spd_data + S.hero.spd_cie[2];
+    float l[3] = {swl.lambda.x, swl.lambda.y, swl.lambda.z}, p[3] = {swl.pdf.x, swl.pdf.y, swl.pdf.z}, v[3] = {sp.x, sp.y, sp.z};
+    V3 sum = mk3(0.f);
+    uint32_t valid = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float x = spd_eval(X, S.hero.spd_cie_interval, l[i]) * v[i], y = spd_eval(Y, S.hero.spd_cie_interval, l[i]) * v[i], z = spd_eval(Z, S.hero.spd_cie_interval, l[i]) * v[i];
+        sum += V3{p[i] == 0.f ? 0.f : x / p[i], p[i] == 0.f ? 0.f : y / p[i], p[i] == 0.f ? 0.f : z / p[i]};
+        valid += p[i] > 0.f ? 1u : 0u;
+    }
+    float factor = 1.f / ((float) valid * S.hero.cie_y_integral);
+    V3 xyz = sum * factor;
+    return {3.240479f * xyz.x + -1.537150f * xyz.y + -0.498535f * xyz.z,
+            -0.969256f * xyz.x + 1.875991f * xyz.y + 0.041556f * xyz.z,
+            0.055648f * xyz.x + -0.204043f * xyz.y + 1.057311f * xyz.z};
+#else
+    return sp;
+#endif
+}
+// a colour slot evaluated to a spectrum: ShaderNodeSlot::eval_albedo_spectrum / eval_illumination_spectrum (shader_node.cpp:317-333)
+VD V3 eval_slot_albedo(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) { return spec_albedo(S, eval_slot3(S, sl, uv, cnt) SWL_A); }
+VD V3 eval_slot_illumination(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) { return spec_illumination(S, eval_slot3(S, sl, uv, cnt) SWL_A); }
+// a number slot that may be an "spd" node in hero mode (metal eta / k, dispersive glass ior): one value per wavelength
+VD V3 eval_slot_spd(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) {
+#if VMK_HERO
+    if (sl.tex == VMK_SLOT_SPD) return spd_eval3(S.hero.spd_data + f2u(sl.v[0]), sl.v[2], swl); // SPDNode::evaluate spd.cpp:36-39
+#endif
+    return eval_slot3(S, sl, uv, cnt);
 }
 
 // =====================================================================================================
@@ -331,8 +485,14 @@ struct Fresnel {
     int kind;
     V3 a, b; // conductor eta,k | schlick F0 | F82 F0,B
     float eta;
+#if VMK_HERO
+    bool eta_sp; // FresnelDielectric over an "spd" ior (dispersive glass): a = the per-wavelength eta, eta = a.x (fresnel.h:83-91)
+#endif
     VD V3 evaluate(float cos_t) const {
         if (kind == FR_CONDUCTOR) return {fresnel_complex(cos_t, a.x, b.x), fresnel_complex(cos_t, a.y, b.y), fresnel_complex(cos_t, a.z, b.z)};
+#if VMK_HERO
+        if (kind == FR_DIELECTRIC && eta_sp) return {fresnel_dielectric(cos_t, a.x), fresnel_dielectric(cos_t, a.y), fresnel_dielectric(cos_t, a.z)};
+#endif
         if (kind == FR_DIELECTRIC) { float f = fresnel_dielectric(cos_t, eta); return {f, f, f}; }
         if (kind == FR_SCHLICK) { // fresnel.h:60-67
             float F_real = fresnel_dielectric(cos_t, eta);
@@ -586,14 +746,17 @@ VD void microfacet_alpha(const DScene &S, const vmk_material *m, int slot_r, int
 VD void lobe_defaults(Lobe &l) {
     l.kind = LB_LAMBERT; l.kr = mk3(1.f); l.rs = mk3(0.f); l.A = 0.f; l.B = 0.f; l.ax = 0.f; l.ay = 0.f;
     l.fr.kind = FR_CONSTANT; l.fr.a = mk3(1.f); l.fr.b = mk3(0.f); l.fr.eta = 1.f;
+#if VMK_HERO
+    l.fr.eta_sp = false;
+#endif
     l.compensate = false; l.weight = 1.f; l.sample_weight = 1.f;
 }
 // create_lobe_set of the single-lobe material plugins
-VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interaction &it, Lobe &l, DCounters &cnt) {
+VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interaction &it, Lobe &l, DCounters &cnt SWL_P) {
     lobe_defaults(l);
     switch (m->type) {
         case VMK_MAT_DIFFUSE: { // diffuse.cpp:21-30, bxdf.cpp:94-101
-            l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A);
             if (m->flags & VMK_MATF_HAS_SIGMA) {
                 float sigma = eval_slot1(S, m->slot[1], it.uv, cnt);
                 sigma = sigma * PiOver2;
@@ -605,7 +768,7 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
             break;
         }
         case VMK_MAT_MIRROR: { // mirror.cpp:60-74
-            l.kind = LB_MICROFACET; l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            l.kind = LB_MICROFACET; l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A);
             microfacet_alpha(S, m, 1, 2, it.uv, 0.0001f, &l.ax, &l.ay, cnt);
             l.compensate = true;
             break;
@@ -613,14 +776,14 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
         case VMK_MAT_METAL: { // metal.cpp:137-156
             l.kind = LB_MICROFACET;
             microfacet_alpha(S, m, 2, 3, it.uv, 0.0001f, &l.ax, &l.ay, cnt);
-            l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot3(S, m->slot[0], it.uv, cnt); l.fr.b = eval_slot3(S, m->slot[1], it.uv, cnt);
+            l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot_spd(S, m->slot[0], it.uv, cnt SWL_A); l.fr.b = eval_slot_spd(S, m->slot[1], it.uv, cnt SWL_A);
             l.compensate = true;
             break;
         }
         case VMK_MAT_PLASTIC: { // plastic.cpp:103-122 (same double roughness_to_alpha as substrate)
             l.kind = LB_PLASTIC;
-            l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
-            V3 Rs = eval_slot3(S, m->slot[1], it.uv, cnt);
+            l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A);
+            V3 Rs = eval_slot_albedo(S, m->slot[1], it.uv, cnt SWL_A);
             float ior = eval_slot1(S, m->slot[2], it.uv, cnt);
             float ax, ay; microfacet_alpha(S, m, 3, 4, it.uv, 0.0001f, &ax, &ay, cnt);
             if (m->flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
@@ -629,9 +792,9 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
             break;
         }
         case VMK_MAT_METALLIC: { // metallic.cpp:42-60: MetallicLobe = PureReflectionLobe with compensation, F82-tint Fresnel
-            l.kind = LB_MICROFACET; l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
+            l.kind = LB_MICROFACET; l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A);
             microfacet_alpha(S, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay, cnt);
-            V3 edge_tint = eval_slot3(S, m->slot[1], it.uv, cnt);
+            V3 edge_tint = eval_slot_albedo(S, m->slot[1], it.uv, cnt SWL_A);
             const float f = 6.f / 7.f;
             const float f5 = pow5(f);
             V3 f_schlick = lerp3(f5, l.kr, mk3(1.f)); // FresnelF82Tint::init_from_F82 fresnel.h:115-121
@@ -640,9 +803,18 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
             break;
         }
         case VMK_MAT_GLASS: { // glass.cpp:240-257, interaction.cpp:80-83
-            l.kind = LB_DIELECTRIC; l.kr = eval_slot3(S, m->slot[0], it.uv, cnt);
-            float ior = eval_slot1(S, m->slot[1], it.uv, cnt);
+            l.kind = LB_DIELECTRIC; l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A);
             float cos_t = dot(it.wo, it.ng);
+#if VMK_HERO
+            if (m->slot[1].tex == VMK_SLOT_SPD) { // dispersive: one ior per wavelength, directions follow the hero wavelength (eta[0])
+                V3 iors = eval_slot_spd(S, m->slot[1], it.uv, cnt SWL_A);
+                iors = cos_t > 0.f ? iors : V3{rcp(iors.x), rcp(iors.y), rcp(iors.z)};
+                microfacet_alpha(S, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay, cnt);
+                l.fr.kind = FR_DIELECTRIC; l.fr.eta = iors.x; l.fr.a = iors; l.fr.eta_sp = true;
+                break;
+            }
+#endif
+            float ior = eval_slot1(S, m->slot[1], it.uv, cnt);
             ior = cos_t > 0.f ? ior : rcp(ior);
             microfacet_alpha(S, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay, cnt);
             l.fr.kind = FR_DIELECTRIC; l.fr.eta = ior;
@@ -650,7 +822,7 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
         }
         default: { // VMK_MAT_SUBSTRATE substrate.cpp:126-149
             l.kind = LB_FRESNEL_BLEND;
-            l.kr = eval_slot3(S, m->slot[0], it.uv, cnt); l.rs = eval_slot3(S, m->slot[1], it.uv, cnt);
+            l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A); l.rs = eval_slot_albedo(S, m->slot[1], it.uv, cnt SWL_A);
             float ax, ay; microfacet_alpha(S, m, 2, 3, it.uv, 0.0001f, &ax, &ay, cnt);
             if (m->flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
             l.ax = clamp_(ax, 0.0001f, 1.f); l.ay = clamp_(ay, 0.0001f, 1.f);
@@ -685,11 +857,11 @@ struct MatCtx {
 // types a scene uses, the megakernel exists in two ahead-of-time variants; the single-lobe variant carries no lobe-set
 // state at all (lower VGPR pressure, no lobe loop).
 template<bool FULL>
-VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &it, MatCtx &mc, DCounters &cnt) {
+VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &it, MatCtx &mc, DCounters &cnt SWL_P) {
     mc.m = m;
     if constexpr (!FULL) {
         mc.n = 1; mc.is_set = false;
-        build_simple_lobe(S, m, it, mc.single, cnt);
+        build_simple_lobe(S, m, it, mc.single, cnt SWL_A);
         return;
     }
     if (m->type == VMK_MAT_MIX) { // mix.cpp:66-71 + LobeSet::create_mix (lobe.cpp:495-508)
@@ -707,16 +879,16 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
     }
     if (m->type != VMK_MAT_PRINCIPLED) {
         mc.n = 1; mc.is_set = false;
-        build_simple_lobe(S, m, it, mc.single, cnt);
+        build_simple_lobe(S, m, it, mc.single, cnt SWL_A);
         return;
     }
     mc.is_set = true;
     V2 uv = it.uv;
-    mc.color = eval_slot3(S, m->slot[VMK_P_COLOR], uv, cnt);
+    mc.color = eval_slot_albedo(S, m->slot[VMK_P_COLOR], uv, cnt SWL_A);
     mc.ior = eval_slot1(S, m->slot[VMK_P_IOR], uv, cnt);
     float roughness = clamp_(eval_slot1(S, m->slot[VMK_P_ROUGHNESS], uv, cnt), 0.0001f, 1.f);
     float anisotropic = eval_slot1(S, m->slot[VMK_P_ANISOTROPIC], uv, cnt);
-    mc.spec_tint = eval_slot3(S, m->slot[VMK_P_SPEC_TINT], uv, cnt);
+    mc.spec_tint = eval_slot_albedo(S, m->slot[VMK_P_SPEC_TINT], uv, cnt SWL_A);
     float aspect = sqrt_(1.f - anisotropic * 0.9f);
     mc.ax = fmax_(0.001f, sqr(roughness) / aspect); mc.ay = fmax_(0.001f, sqr(roughness) * aspect);
     V3 weight = mk3(1.f);
@@ -727,7 +899,7 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
     mc.first = 1;
     if (S.lut_sheen_approx) { // sheen (SheenLTC ctor principled_bsdf.cpp:37-45)
         mc.first = 0;
-        V3 sheen_tint = eval_slot3(S, m->slot[VMK_P_SHEEN_TINT], uv, cnt);
+        V3 sheen_tint = eval_slot_albedo(S, m->slot[VMK_P_SHEEN_TINT], uv, cnt SWL_A);
         float sheen_weight = eval_slot1(S, m->slot[VMK_P_SHEEN_WEIGHT], uv, cnt) * front_factor;
         float sheen_roughness = eval_slot1(S, m->slot[VMK_P_SHEEN_ROUGHNESS], uv, cnt);
         float c[4]; sample_lut2d<4>(S.lut_sheen_approx, cos_t, sheen_roughness, c);
@@ -742,7 +914,7 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
         cc_roughness = sqr(cc_roughness);
         mc.cc_alpha = cc_roughness;
         mc.cc_ior = eval_slot1(S, m->slot[VMK_P_COAT_IOR], uv, cnt);
-        V3 cc_tint = eval_slot3(S, m->slot[VMK_P_COAT_TINT], uv, cnt);
+        V3 cc_tint = eval_slot_albedo(S, m->slot[VMK_P_COAT_TINT], uv, cnt SWL_A);
         mc.kr_coat = (weight * cc_weight) * cc_tint;
         float x = sqrt_(sqrt_(cc_roughness * cc_roughness));
         float z = inverse_lerp(mc.cc_ior, 1.003f, 4.f);
@@ -794,11 +966,11 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
 }
 // expand lobe `i` (0-based within the material's lobe list)
 template<bool FULL>
-VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i, Lobe &l, DCounters &cnt) {
+VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i, Lobe &l, DCounters &cnt SWL_P) {
     if constexpr (!FULL) { l = mc.single; return; }
     const vmk_material *m = mc.m;
     if (m->type == VMK_MAT_MIX || m->type == VMK_MAT_ADD) {
-        build_simple_lobe(S, S.materials + (i == 0 ? m->child0 : m->child1), it, l, cnt);
+        build_simple_lobe(S, S.materials + (i == 0 ? m->child0 : m->child1), it, l, cnt SWL_A);
         l.weight = i == 0 ? mc.mixw[0] : mc.mixw[1]; l.sample_weight = i == 0 ? mc.mixsw[0] : mc.mixsw[1];
         return;
     }
@@ -818,6 +990,7 @@ VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i
 // MaterialEvaluator::albedo (material.cpp:91-98) = LobeSet::albedo (lobe.cpp:564-570) over the per-class Lobe::albedo
 // (bxdf.h:91,153; substrate.cpp:22; lobe.cpp:208-210,308-313; CoatLobe / SpecularLobe principled_bsdf.cpp:154-160,198-205);
 // used by the AOV pass only (frame_buffer.cpp:192-196), always instantiated with FULL = true.
+#if !VMK_HERO
 VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, const Lobe &l, float cos_theta) {
     switch (l.kind) {
         case LB_MICROFACET: {
@@ -846,10 +1019,11 @@ VD V3 mat_albedo(const DScene &S, const MatCtx &mc, const Interaction &it, DCoun
     }
     return sum;
 }
+#endif
 // Lobe::evaluate / LobeSet::evaluate_impl (lobe.cpp:53-75,673-688) in world space; all lobes share it.shading.
 // A single-lobe material is the n = 1 case of the same loop (its weights are 1, so the products are exact).
 template<bool FULL>
-VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Interaction &it, V3 world_wo, V3 world_wi, float *eta, DCounters &cnt) {
+VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Interaction &it, V3 world_wo, V3 world_wi, float *eta, DCounters &cnt SWL_P) {
     V3 wo = it.shading.to_local(world_wo), wi = it.shading.to_local(world_wi);
     if constexpr (!FULL) {
         ScatterEval se = eval_local_call(S, mc.single, wo, wi, eta);
@@ -860,7 +1034,7 @@ VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Inter
     bool sh_world = same_hemisphere(world_wo, world_wi, it.shading.z);
 #pragma unroll 1
     for (int i = 0; i < mc.n; ++i) {
-        Lobe l; mat_lobe<FULL>(S, mc, it, i, l, cnt);
+        Lobe l; mat_lobe<FULL>(S, mc, it, i, l, cnt SWL_A);
         ScatterEval se = eval_local_call(S, l, wo, wi, eta);
         se.f *= abs_cos_theta(wi);
         if (!mc.is_set) { ret = se; break; }
@@ -875,7 +1049,7 @@ VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Inter
 }
 // LobeSet::sample_wi_impl (lobe.cpp:629-658) / Lobe::sample_wi_impl: pick the lobe (3 burnt draws for a set), sample locally
 template<bool FULL>
-VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sampler &sampler, bool *valid, DCounters &cnt) {
+VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sampler &sampler, bool *valid, DCounters &cnt SWL_P) {
     V3 wo = it.shading.to_local(it.wo);
     if constexpr (!FULL) return it.shading.to_world(sample_wi_local_call(mc.single, wo, sampler, valid));
     int strategy = 0;
@@ -892,7 +1066,7 @@ VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sa
         }
         if (mc.n == 1) strategy = 0;
     }
-    Lobe l; mat_lobe<FULL>(S, mc, it, strategy, l, cnt);
+    Lobe l; mat_lobe<FULL>(S, mc, it, strategy, l, cnt SWL_A);
     V3 wi_local = sample_wi_local_call(l, wo, sampler, valid);
     return it.shading.to_world(wi_local);
 }
@@ -900,14 +1074,14 @@ VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sa
 // direct_lighting integrator.cpp:20-37): the two evaluations share ONE instance of the lobe code (2-trip loop).
 template<bool FULL>
 VD void mat_evaluate_and_sample(const DScene &S, const MatCtx &mc, const Interaction &it, V3 wi_light, Sampler &sampler,
-                                ScatterEval &se_light, BSDFSample &bs, DCounters &cnt) {
+                                ScatterEval &se_light, BSDFSample &bs, DCounters &cnt SWL_P) {
     bs.eta = 1.f; bs.wi = mk3(0.f);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         V3 wi = wi_light;
         bool valid = true;
-        if (pass == 1) { wi = mat_sample_wi<FULL>(S, mc, it, sampler, &valid, cnt); bs.wi = wi; }
-        ScatterEval e = mat_evaluate_world<FULL>(S, mc, it, it.wo, wi, pass == 1 ? &bs.eta : nullptr, cnt);
+        if (pass == 1) { wi = mat_sample_wi<FULL>(S, mc, it, sampler, &valid, cnt SWL_A); bs.wi = wi; }
+        ScatterEval e = mat_evaluate_world<FULL>(S, mc, it, it.wo, wi, pass == 1 ? &bs.eta : nullptr, cnt SWL_A);
         e.pdf *= valid ? 1.f : 0.f;
         bool discard = same_hemisphere(it.wo, wi, it.ng) == ((e.flags & flag::Transmission) != 0);
         if (discard) e.pdf = 0.f;
@@ -978,15 +1152,15 @@ VD void light_select(const DScene &S, const vmk_render_params *P, float u, uint3
     *index = light_select_inner(S, P, u);
     *pmf = light_pmf_inner(S, P, *index);
 }
-VD V3 area_L(const DScene &S, const vmk_light *l, V2 uv, V3 ng, V3 w, DCounters &cnt) { // area.cpp:91-95
-    V3 radiance = eval_slot3(S, l->color, uv, cnt) * l->scale;
+VD V3 area_L(const DScene &S, const vmk_light *l, V2 uv, V3 ng, V3 w, DCounters &cnt SWL_P) { // area.cpp:91-95
+    V3 radiance = eval_slot_illumination(S, l->color, uv, cnt SWL_A) * l->scale;
     return radiance * ((dot(w, ng) > 0.f || l->two_sided) ? 1.f : 0.f);
 }
 VD float area_PDF_wi(float pdf_pos, V3 ng, V3 w) { // area.cpp:114-118
     float ret = PDF_wi(pdf_pos, ng, w);
     return (isinf_(ret) || isnan_(ret)) ? 0.f : ret;
 }
-VD LightSample area_sample_wi(const DScene &S, const vmk_render_params *P, const vmk_light *l, V3 p_ref, V2 u, DCounters &cnt) { // area.cpp:120-149
+VD LightSample area_sample_wi(const DScene &S, const vmk_render_params *P, const vmk_light *l, V3 p_ref, V2 u, DCounters &cnt SWL_P) { // area.cpp:120-149
     uint32_t prim; float ur;
     alias_offset_u_remapped(S, l->alias_offset, l->alias_count, u.x, &prim, &ur);
     float pmf = alias_PMF(S, l, prim);
@@ -998,33 +1172,33 @@ VD LightSample area_sample_wi(const DScene &S, const vmk_render_params *P, const
     float pdf_pos = (1.f / it.prim_area) * pmf;
     LightSample ret;
     V3 w = p_ref - it.pos;
-    ret.eval.L = area_L(S, l, it.uv, it.ng, w, cnt);
+    ret.eval.L = area_L(S, l, it.uv, it.ng, w, cnt SWL_A);
     ret.eval.pdf = area_PDF_wi(pdf_pos, it.ng, w);
     ret.p_light = robust_pos(it.pos, it.ng, w, P->ray_offset_factor);
     return ret;
 }
-VD V3 env_L(const DScene &S, const vmk_light *l, V3 local_dir, DCounters &cnt) { // spherical.cpp:60-68
+VD V3 env_L(const DScene &S, const vmk_light *l, V3 local_dir, DCounters &cnt SWL_P) { // spherical.cpp:60-68
     V2 uv = {spherical_phi(local_dir) * Inv2Pi, spherical_theta(local_dir) * InvPi};
-    return eval_slot3(S, l->color, uv, cnt) * l->scale;
+    return eval_slot_illumination(S, l->color, uv, cnt SWL_A) * l->scale;
 }
 VD float env_map_PDF(const DScene &S, const vmk_light *l, V2 p) { // alias2d.cpp:102-106
     uint32_t iu = min((uint32_t) (p.x * (float) l->res_x), l->res_x - 1u);
     uint32_t iv = min((uint32_t) (p.y * (float) l->res_y), l->res_y - 1u);
     return l->alias_integral > 0.f ? S.alias_func[l->cond_offset + iv * l->res_x + iu] / l->alias_integral : 0.f;
 }
-VD LightEval env_evaluate_wi(const DScene &S, const vmk_light *l, V3 p_ref_pos, V3 p_light_pos, DCounters &cnt) { // spherical.cpp:86-103
+VD LightEval env_evaluate_wi(const DScene &S, const vmk_light *l, V3 p_ref_pos, V3 p_light_pos, DCounters &cnt SWL_P) { // spherical.cpp:86-103
     LightEval ret;
     V3 world_dir = normalize(p_light_pos - p_ref_pos);
     V3 local_dir = mul3x3(l->w2o, world_dir);
     float theta = spherical_theta(local_dir), phi = spherical_phi(local_dir);
     float sin_t = sin_(theta);
     V2 uv = {phi * Inv2Pi, theta * InvPi};
-    ret.L = env_L(S, l, local_dir, cnt);
+    ret.L = env_L(S, l, local_dir, cnt SWL_A);
     float pdf = env_map_PDF(S, l, uv) / (_2Pi * Pi * sin_t);
     ret.pdf = sin_t == 0.f ? 0.f : pdf;
     return ret;
 }
-VD LightSample env_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, V2 u, DCounters &cnt) { // spherical.cpp:105-125,162-168; alias2d.cpp:110-129
+VD LightSample env_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, V2 u, DCounters &cnt SWL_P) { // spherical.cpp:105-125,162-168; alias2d.cpp:110-129
     uint32_t iv; float urv;
     alias_offset_u_remapped(S, l->alias_offset, l->alias_count, u.y, &iv, &urv);
     float fv = ((float) iv + urv) / (float) l->alias_count;
@@ -1044,17 +1218,17 @@ VD LightSample env_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, V2 u
     V3 world_dir = normalize(mul3x3(l->o2w, local_dir));
     float pdf_dir = pdf_map / (_2Pi * Pi * sin_t);
     ret.eval.pdf = isinf_(pdf_dir) ? 0.f : pdf_dir;
-    ret.eval.L = env_L(S, l, local_dir, cnt);
+    ret.eval.L = env_L(S, l, local_dir, cnt SWL_A);
     ret.p_light = p_ref + world_dir * l->world_diameter;
     return ret;
 }
 // IPointLight::sample_wi (light.cpp:49-58) with PointLight::Le (point.cpp:43-48) / SpotLight::Le + falloff (spot.cpp:56-79);
 // PDF_wi = -1 marks a delta light (light.h:227-231)
-VD LightSample point_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, DCounters &cnt) {
+VD LightSample point_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, DCounters &cnt SWL_P) {
     LightSample ls;
     V3 pos = ld3(l->position);
     V3 w_un = p_ref - pos;
-    V3 value = eval_slot3(S, l->color, V2{0.f, 0.f}, cnt) * l->scale;
+    V3 value = eval_slot_illumination(S, l->color, V2{0.f, 0.f}, cnt SWL_A) * l->scale;
     if (l->type == VMK_LIGHT_SPOT) {
         V3 w = normalize(w_un);
         float cos_theta = clamp_(dot(ld3(l->direction), w), l->cos_angle, l->cos_falloff_start);
@@ -1065,32 +1239,32 @@ VD LightSample point_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, DC
     ls.p_light = pos;
     return ls;
 }
-VD LightSample light_sample_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, Sampler &sampler, DCounters &cnt) { // lightsampler.cpp:199-216
+VD LightSample light_sample_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, Sampler &sampler, DCounters &cnt SWL_P) { // lightsampler.cpp:199-216
     float u_light = sampler.next_1d();
     V2 u_surface = sampler.next_2d();
     uint32_t index; float pmf;
     light_select(S, P, u_light, &index, &pmf);
     const vmk_light *l = S.lights + index;
     // (point / spot ignore u_surface, light.cpp:49-58)
-    LightSample ls = l->type == VMK_LIGHT_AREA ? area_sample_wi(S, P, l, p_ref, u_surface, cnt)
-                   : (l->type == VMK_LIGHT_SPHERICAL ? env_sample_wi(S, l, p_ref, u_surface, cnt) : point_sample_wi(S, l, p_ref, cnt));
+    LightSample ls = l->type == VMK_LIGHT_AREA ? area_sample_wi(S, P, l, p_ref, u_surface, cnt SWL_A)
+                   : (l->type == VMK_LIGHT_SPHERICAL ? env_sample_wi(S, l, p_ref, u_surface, cnt SWL_A) : point_sample_wi(S, l, p_ref, cnt SWL_A));
     ls.eval.pdf *= pmf;
     return ls;
 }
-VD LightEval light_evaluate_hit_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, const Interaction &it, DCounters &cnt) { // lightsampler.cpp:252-267
+VD LightEval light_evaluate_hit_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, const Interaction &it, DCounters &cnt SWL_P) { // lightsampler.cpp:252-267
     LightEval ret; ret.L = mk3(0.f); ret.pdf = 0.f;
     const vmk_light *l = S.lights + it.light_id;
     if (l->type != VMK_LIGHT_AREA) return ret;
     float pdf_pos = (1.f / it.prim_area) * alias_PMF(S, l, it.prim_id);
     V3 w = p_ref - it.pos;
-    ret.L = area_L(S, l, it.uv, it.ng, w, cnt);
+    ret.L = area_L(S, l, it.uv, it.ng, w, cnt SWL_A);
     ret.pdf = area_PDF_wi(pdf_pos, it.ng, w);
     ret.pdf *= light_select_PMF(S, P, it.light_id);
     return ret;
 }
-VD LightEval light_evaluate_miss_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, V3 wi, DCounters &cnt) { // lightsampler.cpp:290-300
+VD LightEval light_evaluate_miss_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, V3 wi, DCounters &cnt SWL_P) { // lightsampler.cpp:290-300
     const vmk_light *l = S.lights + S.env_light;
-    LightEval ret = env_evaluate_wi(S, l, p_ref, p_ref + wi, cnt);
+    LightEval ret = env_evaluate_wi(S, l, p_ref, p_ref + wi, cnt SWL_A);
     ret.pdf *= light_select_PMF(S, P, S.env_light);
     return ret;
 }

@@ -23,7 +23,7 @@ constexpr int32_t kEmptyRef = 0x7ffffffe;
 constexpr uint32_t kLeafFirstMask = 0x0fffffffu;
 constexpr int kMaxLeafTris = 4;
 
-struct DScene {
+struct DSceneBase {
     const vmk_tri_pos *tri_pos;   // Morton (BVH leaf) order, 48 B each
     const vmk_tri_attr *tri_attr; // same order, 64 B each
     const uint32_t *tri_lookup;   // instance-order global triangle index -> BVH-order index
@@ -44,6 +44,21 @@ struct DScene {
     uint32_t light_alias_offset; // lightsampler/power table (VMK_INVALID when absent)
     float light_alias_integral;
 };
+// hero spectrum only: sRGB uplift table float4[3][64][64][64], tabulated-spectra pool, CIE x, y, z, D65 (vmk_scene)
+struct DSceneHero {
+    const float *rgb2spec;
+    const float *spd_data;
+    uint32_t spd_cie[4];
+    float spd_cie_interval, cie_y_integral;
+};
+// What the host uploads.  The sRGB instance of the kernels reads the DSceneBase prefix only (its per-lane copy of the
+// scene view stays as small as before); the hero instance (VMK_HERO, vmk_hero.hip) sees the tail as well.
+struct DSceneFull : DSceneBase { DSceneHero hero; };
+#if defined(VMK_HERO) && VMK_HERO
+using DScene = DSceneFull;
+#else
+using DScene = DSceneBase;
+#endif
 
 struct DCounters { // per-lane tallies, wave-reduced into vmk_counters at kernel end
     uint32_t closest, shadow, nodes, tris, paths, hits, tex;

@@ -19,9 +19,13 @@
 #include <string>
 #include <vector>
 
-#include "dbvh.h"
+#include "drender.h"
 
 using namespace vmkd;
+
+// the hero-spectrum instance of the megakernel lives in vmk_hero.hip
+hipError_t vmk_hero_occupancy(bool full, bool media, int *blocks_per_cu);
+hipError_t vmk_hero_launch_render(bool full, bool media, unsigned blocks, hipStream_t stream, const void *args, size_t args_bytes);
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -29,11 +33,6 @@ using namespace vmkd;
         if (e_ != hipSuccess) { ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); return VMK_ERR_HIP; } \
     } while (0)
 
-constexpr int kBlock = 256;
-#ifndef VMK_WAVES_PER_SIMD
-#define VMK_WAVES_PER_SIMD 5 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane); measured on classroom with the
-                             // quad traversal: 3: 2015, 4: 2206, 5: 2297, 6: 1825, 8: 1487 Mrays/s
-#endif
 constexpr int kDefaultTile = 32;
 
 // ---------------------------------------------------------------------------------------------------------
@@ -207,283 +206,6 @@ __global__ void k_bvh4_level(const Bvh4Work *in, int n_in, Bvh4Work *out_q, int 
     nodes[w.out] = nd;
     if (leaves) atomicAdd(n_leaves, leaves);
     atomicMax(max_need, w.acc + ns - 1);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// one path vertex: IlluminationIntegrator::Li loop body (base/integral/integrator.cpp:160-311), no media
-// ---------------------------------------------------------------------------------------------------------
-struct PathState {
-    Ray ray;
-    V3 L, T, prev_ng;
-    float scatter_pdf, eta_scale;
-    uint32_t bounces;
-    uint32_t medium; // RayState::medium: the medium the current ray travels in (MEDIA variants only)
-};
-__device__ __forceinline__ void path_begin(PathState &ps, const vmk_render_params *P) {
-    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
-    ps.medium = P->process_mediums ? P->camera_medium : VMK_INVALID; // sensor.cpp:48
-}
-
-// ---- homogeneous medium + Henyey-Greenstein (render_core/medium/homogeneous.cpp:30-70, interaction.h:136-139,
-//      interaction.cpp:12-32,114-134, geometry.cpp:187-199) — §8f rank 1 ----
-VD V3 medium_sigma_t(const vmk_medium *m) { return (ld3(m->sigma_a) + ld3(m->sigma_s)) * m->scale; }
-VD V3 medium_sigma_s(const vmk_medium *m) { return ld3(m->sigma_s) * m->scale; }
-VD V3 exp3(V3 v) { return {exp_(v.x), exp_(v.y), exp_(v.z)}; }
-VD V3 medium_Tr(const vmk_medium *m, float t) { return exp3((-1.f * medium_sigma_t(m)) * fmin_(RayTMax, t)); }
-VD V3 geometry_Tr(const DScene &S, const vmk_render_params *P, const Ray &r, uint32_t medium) {
-    if (P->process_mediums && medium != VMK_INVALID) return medium_Tr(S.mediums + medium, length(r.d) * r.t_max);
-    return mk3(1.f);
-}
-VD float phase_HG(float cos_theta, float g) {
-    float denom = 1.f + sqr(g) + 2.f * g * cos_theta;
-    return Inv4Pi * (1.f - sqr(g)) / (denom * sqrt_(denom));
-}
-VD V3 hg_sample(V3 wo, float g, Sampler &sampler, float *f_out) { // 2 draws
-    V2 u = sampler.next_2d();
-    float sqr_term = (1.f - sqr(g)) / (1.f + g - 2.f * g * u.x);
-    float cos_theta = -(1.f + sqr(g) - sqr(sqr_term)) / (2.f * g);
-    cos_theta = abs_(g) < 1e-3f ? 1.f - 2.f * u.x : cos_theta;
-    float sin_theta = safe_sqrt(1.f - sqr(cos_theta));
-    float phi = 2.f * Pi * u.y;
-    V3 v1, v2;
-    coordinate_system(wo, &v1, &v2);
-    float sp, cp; sincos_(phi, &sp, &cp);
-    V3 wi = sin_theta * cp * v1 + sin_theta * sp * v2 + cos_theta * wo;
-    *f_out = phase_HG(cos_theta, g);
-    return wi;
-}
-// One path vertex for every lane of the wave: ALL lanes call this convergently (the two traversals inside are
-// wave-cooperative), `active` says whether the lane carries a live path.  Returns true when the lane's path ends at this
-// vertex.  `dbg` (tests / ray capture only): 16 floats per vertex —
-// [hit inst, prim, bary.xy | light pdf, bsdf pdf towards the light, sampled pdf, occluded | shadow ray o.xyz d.xyz t_max, traced].
-template<bool FULL, bool MEDIA>
-__device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, WaveScratch *ws, PathState &ps, Sampler &sampler,
-                                            DCounters &cnt, float *dbg, bool active) {
-    const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
-    if (max_depth == 0) return true; // `$for(&bounces, 0, max_depth)` never runs (uniform: P is a kernel argument)
-    Hit hit;
-    if (active) cnt.closest++;
-    bool found = traverse_wave(S, ps.ray, active, false, ws, hit, cnt);
-    if (dbg && active) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
-    bool shade = false; // the lane reached a surface with a material: NEE + scattering follow
-    Interaction it;
-    LightSample ls;
-    Ray shadow_ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
-    if (active && !found) { // evaluate_miss integrator.cpp:137-158
-        if (S.env_light != VMK_INVALID) {
-            LightEval ev = light_evaluate_miss_wi(S, P, ps.ray.o, ps.ray.d, cnt);
-            float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
-            weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
-            ps.L += (ev.L * 1.f * weight) * ps.T;
-        }
-    }
-    bool pass_through = false;
-    bool has_phase = false; // MEDIA: the vertex is a scattering event inside the medium
-    float phase_g = 0.f;
-    uint32_t med_in = VMK_INVALID, med_out = VMK_INVALID; // MediumInterface of the vertex
-    if (active && found) {
-        compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
-        it.wo = normalize(-ps.ray.d);
-        if constexpr (MEDIA) {
-            med_in = S.instances[hit.inst].inside_medium; med_out = S.instances[hit.inst].outside_medium; // geometry.cpp:90
-            ps.ray.t_max = length(it.pos - ps.ray.o) / length(ps.ray.d);                                   // geometry.h:64-69
-            if (P->process_mediums && ps.medium != VMK_INVALID) { // HomogeneousMedium::sample, 2 draws (integrator.cpp:199-206)
-                const vmk_medium *m = S.mediums + ps.medium;
-                V3 sigma_t = medium_sigma_t(m), sigma_s = medium_sigma_s(m);
-                uint32_t channel = (uint32_t) (sampler.next_1d() * 3.f); if (channel > 2u) channel = 2u;
-                float st_c = channel == 0 ? sigma_t.x : (channel == 1 ? sigma_t.y : sigma_t.z);
-                float dist = -log_(1.f - sampler.next_1d()) / st_c;
-                float t = fmin_(dist / length(ps.ray.d), ps.ray.t_max);
-                bool sampled_medium = t < ps.ray.t_max;
-                if (sampled_medium) { // Interaction(ray->at(t), -ray->direction(), true), init_phase, set_medium
-                    it.pos = ps.ray.o + ps.ray.d * t; it.wo = -1.f * ps.ray.d; it.ng = mk3(0.f); it.uv = {0.f, 0.f};
-                    it.mat_id = VMK_INVALID; it.light_id = VMK_INVALID; it.prim_id = VMK_INVALID; it.prim_area = 0.f;
-                    has_phase = true; phase_g = m->g; med_in = ps.medium; med_out = ps.medium;
-                }
-                V3 tr = medium_Tr(m, t);
-                V3 density = sampled_medium ? sigma_t * tr : tr;
-                float pdf = (density.x + density.y + density.z) / 3.f;
-                ps.T *= sampled_medium ? tr * sigma_s / pdf : tr / pdf;
-            }
-        }
-        if (it.mat_id == VMK_INVALID && !has_phase) { // integrator.cpp:208-214: pass through, bounce not counted
-            if constexpr (MEDIA) ps.medium = P->process_mediums ? (dot(it.ng, ps.ray.d) > 0.f ? med_out : med_in) : VMK_INVALID;
-            ps.ray = spawn_ray(it.pos, it.ng, ps.ray.d);
-            pass_through = true;
-        } else {
-            if (!has_phase) cnt.hits++;
-            if (it.light_id != VMK_INVALID) { // integrator.cpp:221-231
-                LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt);
-                float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
-                weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
-                V3 tr = mk3(1.f);
-                if constexpr (MEDIA) tr = geometry_Tr(S, P, ps.ray, ps.medium);
-                ps.L += ev.L * ps.T * weight * tr;
-            }
-            ps.prev_ng = it.ng;
-            // NEE (3 draws) + shadow ray
-            ls = light_sample_wi(S, P, it.pos, sampler, cnt);
-            shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
-            shade = true;
-            cnt.shadow++;
-        }
-    }
-    Hit sh;
-    bool occluded = traverse_wave(S, shadow_ray, shade, true, ws, sh, cnt);
-    if (!shade) return !pass_through;
-    V3 tr_shadow = mk3(1.f);
-    if constexpr (MEDIA) tr_shadow = geometry_Tr(S, P, shadow_ray, P->process_mediums ? (dot(it.ng, shadow_ray.d) > 0.f ? med_out : med_in) : VMK_INVALID);
-    V3 wi = normalize(ls.p_light - it.pos);
-    ScatterEval se; BSDFSample bs;
-    if (MEDIA && has_phase) { // integrator.cpp:271-279: the phase function stands in for the BSDF (2 draws)
-        float f = phase_HG(dot(it.wo, wi), phase_g);
-        se.f = mk3(f); se.pdf = f; se.flags = 0;
-        float fs;
-        bs.wi = hg_sample(it.wo, phase_g, sampler, &fs);
-        bs.eval.f = mk3(fs); bs.eval.pdf = fs; bs.eval.flags = 0; bs.eta = 1.f;
-    } else {
-        // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
-        MatCtx mc;
-        mat_prepare<FULL>(S, S.materials + it.mat_id, it, mc, cnt);
-        mat_evaluate_and_sample<FULL>(S, mc, it, wi, sampler, se, bs, cnt);
-    }
-    if (dbg) {
-        dbg[4] = ls.eval.pdf; dbg[5] = se.pdf; dbg[6] = bs.eval.pdf; dbg[7] = occluded ? 1.f : 0.f;
-        dbg[8] = shadow_ray.o.x; dbg[9] = shadow_ray.o.y; dbg[10] = shadow_ray.o.z; dbg[11] = shadow_ray.d.x; dbg[12] = shadow_ray.d.y;
-        dbg[13] = shadow_ray.d.z; dbg[14] = shadow_ray.t_max; dbg[15] = 1.f;
-    }
-    bool is_delta_light = ls.eval.pdf < 0.f;
-    float weight = mis_mode != 1 ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, se.pdf)) : 1.f;
-    ls.eval.pdf = is_delta_light ? -ls.eval.pdf : ls.eval.pdf;
-    V3 Ld = mk3(0.f);
-    if (!occluded && se.pdf > 0.f && ls.eval.pdf > 0.f) Ld = ls.eval.L * se.f * weight / ls.eval.pdf;
-    if (mis_mode == 2) Ld = Ld * 0.f;
-    ps.L += ps.T * Ld * tr_shadow;
-    ps.eta_scale *= sqr(bs.eta);
-    float lum = max_comp(ps.T);
-    if (!(bs.eval.pdf > 0.f) || lum == 0.f) return true;
-    ps.T *= bs.eval.f / bs.eval.pdf;
-    if (ps.eta_scale * lum < P->rr_threshold && ps.bounces >= min_depth) { // integrator.cpp:292-299
-        float q = fmin_(0.95f, lum);
-        float rr = sampler.next_1d();
-        if (q < rr) return true;
-        ps.T = ps.T / q;
-    }
-    ps.scatter_pdf = bs.eval.pdf;
-    if constexpr (MEDIA) ps.medium = P->process_mediums ? (dot(it.ng, bs.wi) > 0.f ? med_out : med_in) : VMK_INVALID; // interaction.cpp:114-123
-    ps.ray = spawn_ray(it.pos, it.ng, bs.wi);
-    ++ps.bounces;
-    return ps.bounces >= max_depth;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// the megakernel
-// ---------------------------------------------------------------------------------------------------------
-// Work decomposition of one render launch.  A work item is ONE path: item w -> frame frame_begin + w / n_slots of pixel
-// slot w % n_slots (slot = owned tile k, Morton position inside the tile), so consecutive items are neighbouring pixels
-// of the same frame.  Paths write their radiance to the staging plane stage[frame][slot]; k_film_resolve then folds the
-// planes into the accumulation buffer in frame order (the film's running mean is order dependent).  Path-granular
-// items keep every lane busy to the end of the launch however few pixels a GPU owns (1/8 of the image at 8 GPUs is
-// fewer pixels than resident lanes) and whatever the cost spread between pixels.
-struct RenderArgs {
-    const DScene *scene;
-    const vmk_render_params *params;
-    float4 *accum;
-    float4 *stage;        // [frame_count][n_slots]
-    uint32_t *queue;      // work-item counter
-    unsigned long long *counters; // 7 x u64 (vmk_counters layout)
-    uint32_t frame_begin, frame_count;
-    uint32_t tile_size, tile_shift, tiles_x, tiles_y, rank, world;
-    uint32_t n_slots, n_items, chunk; // chunk: items a wave claims with one atomic
-};
-
-__device__ __forceinline__ uint32_t compact_bits(uint32_t v) { // inverse of 2-D Morton interleave (even bits)
-    v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; v = (v | (v >> 8)) & 0x0000FFFFu;
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__device__ __forceinline__ bool slot_to_pixel(const RenderArgs &A, uint32_t slot, uint32_t width, uint32_t height, uint32_t *px, uint32_t *py) {
-    uint32_t k = slot >> (2u * A.tile_shift), r = slot & (A.tile_size * A.tile_size - 1u);
-    uint32_t tile = A.rank + k * A.world;
-    uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
-    *px = tx * A.tile_size + compact_bits(r); *py = ty * A.tile_size + compact_bits(r >> 1);
-    return *px < width && *py < height;
-}
-
-// The MEDIA variants get the 128-register budget of 4 waves per SIMD: at 5 (96 registers) hipcc 7.2 -O3 produced a
-// k_render<true, true> whose medium vertices differed from k_test's instance of the same path_bounce<true, true> and from
-// the oracle (caught by the cbox_media parity test; -O1, 4 waves, or removing the point-light branch all made it agree).
-template<bool FULL, bool MEDIA>
-__global__ __launch_bounds__(kBlock, MEDIA ? 4 : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
-    __shared__ WaveScratch s_ws[kBlock / 64];
-    const DScene S = *A.scene;
-    const vmk_render_params *P = A.params;
-    const uint32_t lane = threadIdx.x & 63u;
-    WaveScratch *ws = s_ws + (threadIdx.x >> 6);
-    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
-
-    // wave-uniform: the part of the wave's claimed chunk not yet handed to a lane
-    uint32_t w_lo = 0, w_hi = 0;
-    bool exhausted = false;
-    // per-lane persistent state
-    bool has_path = false;
-    uint32_t item = 0;
-    Sampler sampler; sampler.state = 0;
-    PathState ps;
-    ps.ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
-    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.prev_ng = mk3(0.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.bounces = 0; ps.medium = VMK_INVALID;
-
-    for (;;) {
-        // ---- hand new paths to idle lanes: ballot + prefix inside the wave, one atomic per chunk ----
-        const unsigned long long need_mask = __ballot(!has_path);
-        if (need_mask && (w_lo < w_hi || !exhausted)) {
-            if (w_lo >= w_hi) {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(A.queue, A.chunk);
-                b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
-                w_lo = min(b, A.n_items); w_hi = (uint32_t) min((unsigned long long) b + A.chunk, (unsigned long long) A.n_items);
-                if ((unsigned long long) b + A.chunk >= A.n_items) exhausted = true;
-            }
-            if (!has_path) {
-                uint32_t w = w_lo + (uint32_t) __popcll(need_mask & ((1ull << lane) - 1ull));
-                if (w < w_hi) {
-                    uint32_t f = w / A.n_slots, slot = w - f * A.n_slots, px, py;
-                    if (slot_to_pixel(A, slot, P->width, P->height, &px, &py)) {
-                        // ray generation (rt_geom kernel of the reference, frame_buffer.cpp:172-177)
-                        uint32_t frame = A.frame_begin + f;
-                        sampler.start(px, py, frame, 0);
-                        ps.ray = generate_ray(P, px, py, sampler);
-                        sampler.start(px, py, frame, 1); // path_tracing kernel, integrator.cpp:93
-                        path_begin(ps, P);
-                        has_path = true; item = w;
-                        cnt.paths++;
-                    }
-                }
-            }
-            w_lo = min(w_lo + (uint32_t) __popcll(need_mask), w_hi);
-        }
-        if (!__any(has_path) && exhausted && w_lo >= w_hi) break;
-
-        // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
-        // (all lanes take part: the traversals inside are wave-cooperative; lanes without a path contribute no ray)
-        bool terminate = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
-        if (has_path && terminate) {
-            A.stage[item] = make_float4(ps.L.x, ps.L.y, ps.L.z, 1.f);
-            has_path = false;
-        }
-    }
-    // ---- counters: one atomic per wave and counter ----
-    uint32_t c[7] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris, cnt.paths, cnt.hits, cnt.tex};
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        uint32_t s = wave_sum(c[i]);
-        if (lane == 0 && s) atomicAdd(A.counters + i, (unsigned long long) s);
-    }
 }
 
 // RGBFilm accumulation (frame_buffer.cpp:117-126): acc = lerp(1/(f+1), acc, L_f), frame by frame for every owned pixel
@@ -794,6 +516,8 @@ struct vmk_ctx {
     // scene
     bool scene_ready{false}, accel_ready{false}, params_ready{false};
     bool full_materials{true}; // scene has mix / principled_bsdf -> lobe-set variant of the megakernel
+    bool hero{false};          // vmk_scene::spectrum == VMK_SPECTRUM_HERO -> the vmk_hero.hip instance of the megakernel
+    DevBuf<float> rgb2spec, spd;
     uint32_t n_tris{0};
     DevBuf<vmk_tri_pos> tri_pos_in, tri_pos;
     DevBuf<vmk_tri_attr> tri_attr_in, tri_attr;
@@ -809,8 +533,8 @@ struct vmk_ctx {
     DevBuf<float> alias_prob, alias_func, srgb_lut, luts;
     DevBuf<uint32_t> alias_idx;
     DevBuf<BvhNode> nodes;
-    DevBuf<DScene> d_scene;
-    DScene h_scene{};
+    DevBuf<DSceneFull> d_scene; // DSceneBase prefix + hero tail (dscene.h)
+    DSceneFull h_scene{};
     float world_min[3]{}, world_max[3]{};
     vmk_accel_info accel{};
     // render state
@@ -861,7 +585,7 @@ void vmk_destroy(vmk_ctx *ctx) {
     (void) hipStreamSynchronize(ctx->stream);
     ctx->tri_pos_in.release(); ctx->tri_pos.release(); ctx->tri_attr_in.release(); ctx->tri_attr.release(); ctx->tri_lookup.release();
     ctx->instances.release(); ctx->materials.release(); ctx->lights.release(); ctx->mediums.release(); ctx->textures.release(); ctx->tex_data.release();
-    ctx->alias_prob.release(); ctx->alias_func.release(); ctx->alias_idx.release(); ctx->srgb_lut.release(); ctx->luts.release();
+    ctx->alias_prob.release(); ctx->alias_func.release(); ctx->alias_idx.release(); ctx->srgb_lut.release(); ctx->luts.release(); ctx->rgb2spec.release(); ctx->spd.release();
     ctx->nodes.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release(); ctx->stage.release();
     ctx->queue.release(); ctx->counters.release();
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
@@ -883,11 +607,29 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
         if ((in.mat_id != VMK_INVALID && in.mat_id >= sc->n_materials) || (in.light_id != VMK_INVALID && in.light_id >= sc->n_lights) || (uint64_t) in.tri_offset + in.tri_count > sc->n_tris) { ctx->error = "vmk_upload_scene: instance table references out-of-range rows"; return VMK_ERR_ARG; }
     }
     for (uint32_t i = 0; i < sc->n_tris; ++i) if (sc->tri_pos[i].inst >= sc->n_instances) { ctx->error = "vmk_upload_scene: triangle references a missing instance"; return VMK_ERR_ARG; }
-    auto slot_ok = [&](const vmk_slot &s) { return s.tex == VMK_INVALID || (s.tex & 0xffffu) < sc->n_textures; };
+    const bool hero = sc->spectrum == VMK_SPECTRUM_HERO;
+    if (sc->spectrum != VMK_SPECTRUM_SRGB && !hero) { ctx->error = "vmk_upload_scene: unknown spectrum type"; return VMK_ERR_ARG; }
+    auto spd_ok = [&](uint32_t off, uint32_t n) { return n >= 2 && (uint64_t) off + n <= sc->n_spd; };
+    if (hero) {
+        if (!sc->rgb2spec || !sc->spd_data || sc->spd_cie_count < 2 || !(sc->spd_cie_interval > 0.f) || !(sc->cie_y_integral > 0.f)) { ctx->error = "vmk_upload_scene: hero spectrum tables missing"; return VMK_ERR_ARG; }
+        for (int k = 0; k < 4; ++k) if (!spd_ok(sc->spd_cie[k], sc->spd_cie_count)) { ctx->error = "vmk_upload_scene: CIE tables out of range"; return VMK_ERR_ARG; }
+        // SPD::eval reads samples [0, uint(470 / interval) + 1): must stay inside the table
+        if ((uint32_t) (470.f / sc->spd_cie_interval) + 1u > sc->spd_cie_count) { ctx->error = "vmk_upload_scene: CIE table interval inconsistent"; return VMK_ERR_ARG; }
+    }
+    auto slot_ok = [&](const vmk_slot &s) { return s.tex == VMK_INVALID || (s.tex != VMK_SLOT_SPD && (s.tex & 0xffffu) < sc->n_textures); };
+    auto spd_slot_ok = [&](const vmk_slot &s) { // "spd" nodes: metal eta / k and the ior of a dispersive glass, hero spectrum only
+        uint32_t off, n; std::memcpy(&off, &s.v[0], 4); std::memcpy(&n, &s.v[1], 4);
+        return hero && spd_ok(off, n) && s.v[2] > 0.f && (uint32_t) (470.f / s.v[2]) + 1u <= n;
+    };
     for (uint32_t i = 0; i < sc->n_materials; ++i) {
         const vmk_material &m = sc->materials[i];
         if (m.type > VMK_MAT_PLASTIC) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
-        for (auto &s : m.slot) if (!slot_ok(s)) { ctx->error = "vmk_upload_scene: material slot references a missing texture"; return VMK_ERR_ARG; }
+        for (int k = 0; k < VMK_MAX_SLOTS; ++k) {
+            const vmk_slot &s = m.slot[k];
+            const bool spd_allowed = (m.type == VMK_MAT_METAL && k < 2) || (m.type == VMK_MAT_GLASS && k == 1);
+            if (s.tex == VMK_SLOT_SPD ? !(spd_allowed && spd_slot_ok(s)) : !slot_ok(s)) { ctx->error = "vmk_upload_scene: material slot references a missing texture or spectrum"; return VMK_ERR_ARG; }
+        }
+        if ((m.flags & VMK_MATF_DISPERSIVE) && !(m.type == VMK_MAT_GLASS && m.slot[1].tex == VMK_SLOT_SPD)) { ctx->error = "vmk_upload_scene: VMK_MATF_DISPERSIVE without a tabulated ior"; return VMK_ERR_ARG; }
         if (m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD) {
             if (m.child0 >= sc->n_materials || m.child1 >= sc->n_materials) { ctx->error = "vmk_upload_scene: mix child out of range"; return VMK_ERR_ARG; }
             uint32_t t0 = sc->materials[m.child0].type, t1 = sc->materials[m.child1].type;
@@ -946,8 +688,18 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     HIP_TRY(ctx->luts.alloc(total));
     size_t off[6], o = 0;
     for (int i = 0; i < 6; ++i) { off[i] = o; if (src[i]) HIP_TRY(hipMemcpyAsync(ctx->luts.p + o, src[i], sizes[i] * 4, hipMemcpyHostToDevice, st)); o += sizes[i]; }
-    DScene &h = ctx->h_scene;
-    h = DScene{};
+    ctx->hero = hero;
+    if (hero) {
+        HIP_TRY(ctx->rgb2spec.upload(sc->rgb2spec, (size_t) 3 * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * 4, st));
+        HIP_TRY(ctx->spd.upload(sc->spd_data, sc->n_spd, st));
+    }
+    DSceneFull &h = ctx->h_scene;
+    h = DSceneFull{};
+    if (hero) {
+        h.hero.rgb2spec = ctx->rgb2spec.p; h.hero.spd_data = ctx->spd.p;
+        for (int k = 0; k < 4; ++k) h.hero.spd_cie[k] = sc->spd_cie[k];
+        h.hero.spd_cie_interval = sc->spd_cie_interval; h.hero.cie_y_integral = sc->cie_y_integral;
+    }
     h.instances = ctx->instances.p; h.materials = ctx->materials.p; h.lights = ctx->lights.p; h.mediums = ctx->mediums.p; h.textures = ctx->textures.p; h.tex_data = ctx->tex_data.p;
     h.alias_prob = ctx->alias_prob.p; h.alias_idx = ctx->alias_idx.p; h.alias_func = ctx->alias_func.p; h.srgb_lut = ctx->srgb_lut.p;
     h.lut_pure_reflection = ctx->luts.p + off[0]; h.lut_dielectric = ctx->luts.p + off[1]; h.lut_dielectric_inv = ctx->luts.p + off[2];
@@ -1071,7 +823,7 @@ int vmk_build_accel(vmk_ctx *ctx) {
 #undef BUILD_TRY
     if (h_nodes > n_int) { ctx->error = "vmk_build_accel: BVH4 node count exceeds the allocation"; return VMK_ERR_STATE; }
     if (h_scalars[0] > kQuadStack) { ctx->error = "vmk_build_accel: worst-case traversal stack need " + std::to_string(h_scalars[0]) + " exceeds the per-ray LDS stack (" + std::to_string(kQuadStack) + ")"; return VMK_ERR_UNSUPPORTED; }
-    DScene &h = ctx->h_scene;
+    DSceneFull &h = ctx->h_scene;
     h.tri_pos = ctx->tri_pos.p; h.tri_attr = ctx->tri_attr.p; h.tri_lookup = ctx->tri_lookup.p; h.nodes = ctx->nodes.p;
     h.root = n <= (uint32_t) kMaxLeafTris ? (int32_t) ~((uint32_t) 0 | ((n - 1u) << 28)) : 0;
     HIP_TRY(ctx->d_scene.upload(&h, 1, st));
@@ -1164,7 +916,8 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     int per_cu = 0;
     const bool media = ctx->params.process_mediums != 0;
     auto kernel = ctx->full_materials ? (media ? k_render<true, true> : k_render<true, false>) : (media ? k_render<false, true> : k_render<false, false>);
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
+    if (ctx->hero) HIP_TRY(vmk_hero_occupancy(ctx->full_materials, media, &per_cu));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
     if (kernel_ms) HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     for (uint32_t done = 0; done < frame_count; done += per_launch) {
@@ -1176,8 +929,11 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         uint64_t chunk = (n_items / ((uint64_t) grid * (kBlock / 64) * 8)) & ~63ull;
         A.chunk = (uint32_t) std::max<uint64_t>(64, std::min<uint64_t>(1024, chunk));
         HIP_TRY(hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
-        HIP_TRY(hipGetLastError());
+        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, grid, ctx->stream, &A, sizeof(A)));
+        else {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
+            HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_film_resolve, dim3((A.n_slots + 255) / 256), dim3(256), 0, ctx->stream, A);
         HIP_TRY(hipGetLastError());
     }
@@ -1296,6 +1052,7 @@ static bool inverse4(const float *m, float *out) {
 int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba, float *depth, float *motion_xy) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready) { ctx->error = "vmk_render_aov: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    if (ctx->hero) { ctx->error = "vmk_render_aov: the G-buffer kernel is the sRGB instance; a hero-spectrum scene is uploaded"; return VMK_ERR_UNSUPPORTED; }
     if (ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_render_aov: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t) ctx->params.width * ctx->params.height;
@@ -1353,6 +1110,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     if ((kind == 6 || kind == 7) && ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_test_eval: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     if ((kind == 6 || kind == 7) && ctx->params.process_mediums && ctx->params.camera_medium != VMK_INVALID && ctx->params.camera_medium >= ctx->n_mediums) { ctx->error = "vmk_test_eval: camera medium out of range"; return VMK_ERR_ARG; }
     if (kind == 5 && !ctx->params_ready) { ctx->error = "vmk_test_eval: kind 5 needs render params"; return VMK_ERR_STATE; }
+    if ((kind == 4 || kind == 6 || kind == 7) && ctx->hero) { ctx->error = "vmk_test_eval: the material / path unit kernels are the sRGB instance; a hero-spectrum scene is uploaded"; return VMK_ERR_UNSUPPORTED; }
     if (kind == 4) { // material ids are validated here: the kernel indexes materials[] with them
         uint32_t n_mat = (uint32_t) ctx->materials.n;
         for (uint32_t i = 0; i < n; ++i) { uint32_t id; std::memcpy(&id, in + (size_t) i * in_stride, 4); if (id >= n_mat) { ctx->error = "vmk_test_eval: material id out of range"; return VMK_ERR_ARG; } }
@@ -1380,6 +1138,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
 int vmk_self_check(vmk_ctx *ctx, uint32_t max_pixels, uint32_t *n_checked, uint32_t *n_mismatch) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready || !ctx->fb) { ctx->error = "vmk_self_check: scene/accel/params not ready"; return VMK_ERR_STATE; }
+    if (ctx->hero) { ctx->error = "vmk_self_check: the unit kernel is the sRGB instance; a hero-spectrum scene is uploaded"; return VMK_ERR_UNSUPPORTED; }
     if (n_checked) *n_checked = 0;
     if (n_mismatch) *n_mismatch = 0;
     const uint32_t w = ctx->params.width, h = ctx->params.height;

@@ -1,0 +1,27 @@
+// vmk_hero.hip — the megakernel compiled for the hero-wavelength spectrum (render_core/spectrum/hero.cpp).
+//
+// Vision JIT-compiles its path-tracing kernel against the scene's Spectrum plugin; here the two spectra are two
+// ahead-of-time instances of the same source (drender.h and the headers under it): this translation unit sets
+// VMK_HERO = 1 and renames the device namespace, so that the sRGB instance in vmk.hip — the one the headline benchmark
+// runs — keeps exactly the code, register budget and symbols it has without this file.  libvmk.so links both.
+#define VMK_HERO 1
+#define vmkd vmkd_hero
+#include "drender.h"
+
+#include <cstring>
+
+hipError_t vmk_hero_occupancy(bool full, bool media, int *blocks_per_cu) {
+    using namespace vmkd;
+    auto kernel = full ? (media ? k_render<true, true> : k_render<true, false>) : (media ? k_render<false, true> : k_render<false, false>);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, kBlock, 0);
+}
+// Launch k_render<FULL, MEDIA> of the hero instance.  `args` points at vmk.hip's RenderArgs (same declaration, same layout).
+hipError_t vmk_hero_launch_render(bool full, bool media, unsigned blocks, hipStream_t stream, const void *args, size_t args_bytes) {
+    using namespace vmkd;
+    RenderArgs A;
+    if (args_bytes != sizeof(A)) return hipErrorInvalidValue;
+    std::memcpy(&A, args, sizeof(A));
+    auto kernel = full ? (media ? k_render<true, true> : k_render<true, false>) : (media ? k_render<false, true> : k_render<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, A);
+    return hipGetLastError();
+}

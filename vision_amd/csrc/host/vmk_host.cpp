@@ -9,6 +9,7 @@
 //   Geometry::update_instances / upload                                                      base/mgr/geometry.cpp:20-34,64-71
 #include "../../../include/vmk_host.h"
 #include "json.h"
+#include "rgb2spec_opt.h"
 
 #include <algorithm>
 #include <cmath>
@@ -204,6 +205,7 @@ static void procedural_sky(Image &img) {
 // scene builder
 // ------------------------------------------------------------------------------------------------
 struct MetalIor { const char *name; float eta[3]; float k[3]; };
+struct MetalSpd { std::string name; std::vector<float> eta, k; };
 static const MetalIor kMetals[] = {
 #include "metal_ior_rgb.inl"
 };
@@ -257,6 +259,13 @@ struct HostScene {
     std::vector<float> alias_prob, alias_func;
     std::vector<uint32_t> alias_idx;
     std::vector<float> luts;
+    // hero spectrum (render_core/spectrum/hero.cpp): tabulated spectra pool, CIE tables, metal (eta, k) curves, sRGB uplift table
+    bool hero{false};
+    std::string data_dir;            // directory of the albedo-table blob: spectra.bin / srgb2spec.bin live next to it
+    std::vector<float> spd;          // vmk_scene.spd_data
+    std::vector<float> cie_raw;      // X, Y, Z, D65 at 1 nm (4 x 471)
+    std::vector<MetalSpd> metal_spd;
+    std::vector<float> rgb2spec;
     vmk_scene scene{};
     vmk_render_params params{};
     uint32_t output_spp{0};
@@ -304,6 +313,75 @@ struct HostScene {
         textures.push_back(t);
         tex_index[key] = id;
         return id;
+    }
+
+    // ---- tabulated spectra ("spd" shader node, SPD::init spd.cpp:50-53) ----
+    vmk_slot add_spd(const std::vector<float> &func) {
+        vmk_slot sl{};
+        uint32_t off = (uint32_t) spd.size(), n = (uint32_t) func.size();
+        spd.insert(spd.end(), func.begin(), func.end());
+        std::memcpy(&sl.v[0], &off, 4); std::memcpy(&sl.v[1], &n, 4);
+        sl.v[2] = 471.f / (float) n; // static_cast<float>(cie_sample_count) / func.size()
+        sl.tex = VMK_SLOT_SPD;
+        return sl;
+    }
+    void load_spectra() {
+        std::string path = join_path(data_dir, "spectra.bin");
+        std::ifstream f(path, std::ios::binary);
+        if (!f) fail("spectrum/hero: cannot open '" + path + "' (CIE observer, D65 and metal curves; tools/make_spectra.py)");
+        uint32_t hdr[3];
+        f.read((char *) hdr, sizeof(hdr));
+        if (!f || hdr[0] != 0x44505356u || hdr[1] != 1u || hdr[2] != 471u) fail("bad spectra blob '" + path + "'");
+        cie_raw.resize(4 * 471);
+        f.read((char *) cie_raw.data(), (std::streamsize) (cie_raw.size() * 4));
+        uint32_t n_metals = 0;
+        f.read((char *) &n_metals, 4);
+        if (!f || n_metals > 64) fail("spectra blob truncated");
+        for (uint32_t i = 0; i < n_metals; ++i) {
+            char name[17] = {0}; uint32_t n = 0;
+            f.read(name, 16); f.read((char *) &n, 4);
+            if (!f || n < 2 || n > 4096) fail("spectra blob: bad metal record");
+            MetalSpd m; m.name = name; m.eta.resize(n); m.k.resize(n);
+            f.read((char *) m.eta.data(), (std::streamsize) n * 4); f.read((char *) m.k.data(), (std::streamsize) n * 4);
+            if (!f) fail("spectra blob truncated");
+            metal_spd.push_back(std::move(m));
+        }
+    }
+    void load_rgb2spec() {
+        std::string path = join_path(data_dir, "srgb2spec.bin");
+        std::ifstream f(path, std::ios::binary);
+        if (!f) fail("spectrum/hero: cannot open '" + path + "' (sRGB uplift table; python __graft_entry__.py builds it with vmk_host_build_rgb2spec)");
+        uint32_t hdr[3];
+        f.read((char *) hdr, sizeof(hdr));
+        const size_t n = (size_t) 3 * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * 4;
+        if (!f || hdr[0] != 0x53325256u || hdr[1] != 1u || hdr[2] != VMK_RGB2SPEC_RES) fail("bad sRGB uplift table '" + path + "'");
+        rgb2spec.resize(n);
+        f.read((char *) rgb2spec.data(), (std::streamsize) (n * 4));
+        if (!f) fail("sRGB uplift table truncated");
+    }
+    // HeroWavelengthSpectrum ctor (hero.cpp:243-252): the CIE tables downsampled to every 5th 1 nm sample (spd.cpp:27-33,95-109)
+    void init_hero() {
+        hero = true;
+        load_spectra();
+        load_rgb2spec();
+        const uint32_t interval = 5;
+        const float factor = (830.0f - 360.0f) / (float) interval;
+        const uint32_t n = (uint32_t) std::ceil(factor);
+        for (int t = 0; t < 4; ++t) {
+            std::vector<float> samples(n);
+            for (uint32_t x = 0; x < n; ++x) samples[x] = cie_raw[(size_t) t * 471 + x * interval];
+            vmk_slot sl = add_spd(samples);
+            std::memcpy(&scene.spd_cie[t], &sl.v[0], 4);
+            scene.spd_cie_count = n; scene.spd_cie_interval = sl.v[2];
+        }
+        { // densely_sampled_spectrum_integral(5, cie::Y) spd.cpp:15-25
+            const float *Y = cie_raw.data() + 471;
+            float sum = 0.0f, tt = (float) interval;
+            float nf = (830.0f - 360.0f) / tt;
+            uint32_t nn = (uint32_t) nf + 1u;
+            for (uint32_t i = 0; i < nn - 1u; ++i) sum += 0.5f * (Y[i * interval] + Y[(i + 1u) * interval]);
+            scene.cie_y_integral = sum * tt;
+        }
     }
 
     // ---- slots: SlotDesc::init / ShaderNodeDesc::init (node_desc.cpp:128-151,307-335), swizzle shader_node.cpp:242-273 ----
@@ -376,6 +454,12 @@ struct HostScene {
             for (auto &k : kMetals) if (mname == k.name) mi = &k;
             m.slot[0].v[0] = mi->eta[0]; m.slot[0].v[1] = mi->eta[1]; m.slot[0].v[2] = mi->eta[2];
             m.slot[1].v[0] = mi->k[0]; m.slot[1].v[1] = mi->k[1]; m.slot[1].v[2] = mi->k[2];
+            if (hero) { // is_complete(): the measured curves travel as "spd" nodes (metal.cpp:113-117)
+                const MetalSpd *ms = &metal_spd.at(0);
+                for (auto &k : metal_spd) if (k.name == "Ag") ms = &k; // names[0] of the sorted map when the name is unknown
+                for (auto &k : metal_spd) if (mname == k.name) ms = &k;
+                m.slot[0] = add_spd(ms->eta); m.slot[1] = add_spd(ms->k);
+            }
             m.slot[2] = parse_slot(p, "roughness", 1, {0.01f}); m.slot[3] = parse_slot(p, "anisotropic", 1, {0.f});
         } else if (type == "glass") { // glass.cpp:189-196,216-233
             m.type = VMK_MAT_GLASS;
@@ -383,10 +467,19 @@ struct HostScene {
             std::string gname = p["material_name"].as_string();
             if (gname.empty()) m.slot[1] = parse_slot(p, "ior", 1, {1.5f});
             else { // Sellmeier at rgb_spectrum_peak_wavelengths.x (glass.cpp:104-134,226-228)
-                float lambda = 602.785f / 1000.f; float l2 = lambda * lambda, f;
-                if (gname == "LASF9") f = 2.00029547f * l2 / (l2 - 0.0121426017f) + 0.298926886f * l2 / (l2 - 0.0538736236f) + 1.80691843f * l2 / (l2 - 156.530829f);
-                else f = 1.03961212f * l2 / (l2 - 0.00600069867f) + 0.231792344f * l2 / (l2 - 0.0200179144f) + 1.01046945f * l2 / (l2 - 103.560653f);
-                m.slot[1].v[0] = std::sqrt(f + 1.f);
+                auto sellmeier = [&](float lambda_nm) {
+                    float lambda = lambda_nm / 1000.f; float l2 = lambda * lambda, f;
+                    if (gname == "LASF9") f = 2.00029547f * l2 / (l2 - 0.0121426017f) + 0.298926886f * l2 / (l2 - 0.0538736236f) + 1.80691843f * l2 / (l2 - 156.530829f);
+                    else f = 1.03961212f * l2 / (l2 - 0.00600069867f) + 0.231792344f * l2 / (l2 - 0.0200179144f) + 1.01046945f * l2 / (l2 - 103.560653f);
+                    return std::sqrt(f + 1.f);
+                };
+                m.slot[1].v[0] = sellmeier(602.785f);
+                if (hero) { // is_complete(): the curve tabulated by SPD::to_list (spd.h:41-47), is_dispersive() (glass.cpp:221-224,234)
+                    std::vector<float> lst;
+                    for (float lambda = 360.0f; lambda < 830.0f; lambda += 5.f) lst.push_back(sellmeier(lambda));
+                    m.slot[1] = add_spd(lst);
+                    m.flags |= VMK_MATF_DISPERSIVE;
+                }
             }
             m.slot[2] = parse_slot(p, "roughness", 1, {0.5f}); m.slot[3] = parse_slot(p, "anisotropic", 1, {0.f});
         } else if (type == "substrate") { // substrate.cpp:117-124
@@ -582,9 +675,11 @@ struct HostScene {
         double min_world_radius = rs["min_world_radius"].as_double(10.0);
         const Json &spec = root["spectrum"];
         std::string spec_type = spec["type"].as_string("srgb");
-        if (spec_type != "srgb") fail("spectrum/" + spec_type + " is a §8(f) 'next' row (needs the stripped srgb2spec table); only spectrum/srgb is in scope");
-        if (spec["param"]["dimension"].as_uint(3) != 3) fail("spectrum/srgb requires dimension 3");
-        describe("spectrum", "srgb", "");
+        if (opt.spectrum == 1) spec_type = "srgb"; else if (opt.spectrum == 2) spec_type = "hero";
+        if (spec_type != "srgb" && spec_type != "hero") fail("spectrum/" + spec_type + " is outside the hot-path scope (srgb, hero)");
+        if (spec["param"]["dimension"].as_uint(3) != 3) fail("spectrum/" + spec_type + " with dimension != 3 is outside the hot-path scope (paths carry three wavelengths)");
+        if (spec_type == "hero" && !list_only) init_hero();
+        describe("spectrum", spec_type, "");
         // mediums (scene_desc.cpp:26-35, MediumDesc::init node_desc.cpp:182-197, homogeneous.cpp:20-24)
         uint32_t global_medium = VMK_INVALID;
         params.process_mediums = 0; params.camera_medium = VMK_INVALID;
@@ -957,6 +1052,8 @@ struct HostScene {
         scene.lights = lights.data(); scene.textures = textures.data(); scene.tex_data = tex_data.data(); scene.tex_bytes = tex_data.size();
         scene.alias_prob = alias_prob.data(); scene.alias_idx = alias_idx.data(); scene.alias_func = alias_func.data();
         for (int k = 0; k < 3; ++k) { scene.world_min[k] = (float) bmin[k]; scene.world_max[k] = (float) bmax[k]; }
+        scene.spectrum = hero ? VMK_SPECTRUM_HERO : VMK_SPECTRUM_SRGB;
+        scene.rgb2spec = hero ? rgb2spec.data() : nullptr; scene.spd_data = hero ? spd.data() : nullptr; scene.n_spd = (uint32_t) spd.size();
         // sheen needs the LTC tables; without them only sheen_weight == 0 (constant) is accepted
         if (!scene.luts.sheen_approx)
             for (auto &m : materials) if (m.type == VMK_MAT_PRINCIPLED && (m.slot[VMK_P_SHEEN_WEIGHT].tex != VMK_INVALID || m.slot[VMK_P_SHEEN_WEIGHT].v[0] != 0.f))
@@ -1004,6 +1101,7 @@ int vmk_host_load_scene(const char *json_path, const vmk_host_options *opt, vmk_
         if (opt) h->hs.opt = *opt; else { h->hs.opt.max_depth = -1; h->hs.opt.min_depth = -1; }
         std::string lut = opt && opt->lut_path ? opt->lut_path : "";
         h->hs.opt.lut_path = lut.empty() ? nullptr : lut.c_str();
+        h->hs.data_dir = dir_of(lut);
         h->hs.load_luts();
         h->hs.load(json_path);
         h->hs.finalize();
@@ -1018,5 +1116,24 @@ const vmk_render_params *vmk_host_render_params(const vmk_host_scene *scene) { r
 uint32_t vmk_host_output_spp(const vmk_host_scene *scene) { return scene ? scene->hs.output_spp : 0; }
 const char *vmk_host_output_fn(const vmk_host_scene *scene) { return scene ? scene->hs.output_fn.c_str() : ""; }
 const char *vmk_host_describe(const vmk_host_scene *scene) { return scene ? scene->hs.description.c_str() : ""; }
+
+int vmk_host_build_rgb2spec(const char *spectra_path, const char *out_path, uint32_t threads) {
+    if (!spectra_path || !out_path) { g_error = "vmk_host_build_rgb2spec: bad argument"; return VMK_ERR_ARG; }
+    std::ifstream f(spectra_path, std::ios::binary);
+    uint32_t hdr[3] = {0, 0, 0};
+    f.read((char *) hdr, sizeof(hdr));
+    std::vector<float> cie(4 * 471);
+    f.read((char *) cie.data(), (std::streamsize) (cie.size() * 4));
+    if (!f || hdr[0] != 0x44505356u || hdr[1] != 1u || hdr[2] != 471u) { g_error = std::string("vmk_host_build_rgb2spec: bad spectra blob '") + spectra_path + "'"; return VMK_ERR_ARG; }
+    const size_t n = (size_t) 3 * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * 4;
+    std::vector<float> table(n);
+    rgb2spec::optimise(cie.data(), table.data(), threads);
+    std::ofstream o(out_path, std::ios::binary);
+    const uint32_t ohdr[3] = {0x53325256u, 1u, VMK_RGB2SPEC_RES}; // 'VR2S'
+    o.write((const char *) ohdr, sizeof(ohdr));
+    o.write((const char *) table.data(), (std::streamsize) (n * 4));
+    if (!o) { g_error = std::string("vmk_host_build_rgb2spec: cannot write '") + out_path + "'"; return VMK_ERR_ARG; }
+    return VMK_OK;
+}
 
 }// extern "C"

@@ -93,11 +93,12 @@ class Pipeline:
     """pipeline/fixed.  `Pipeline(scene_json)` plays Importer::import_scene + init_scene."""
 
     def __init__(self, scene_file, device=0, width=0, height=0, max_depth=-1, min_depth=-1, procedural_env=True,
-                 drop_unsupported_lights=False, mediums=False):
+                 drop_unsupported_lights=False, mediums=False, spectrum=None):
         self._mediums = mediums
+        self._spectrum = spectrum  # None: the scene's own "spectrum" block; "srgb" / "hero" override it
         self.host_scene = HostScene(scene_file, width=width, height=height, max_depth=max_depth, min_depth=min_depth,
                                     procedural_env=procedural_env, drop_unsupported_lights=drop_unsupported_lights,
-                                    mediums=mediums)
+                                    mediums=mediums, spectrum=spectrum)
         self.params = self.host_scene.params_copy()
         self.backend = Backend(device)
         self.frame_buffer = FrameBuffer(self)
@@ -131,7 +132,7 @@ class Pipeline:
         path = self.host_scene.json_path
         self.host_scene.close()
         self.host_scene = HostScene(path, width=width, height=height, max_depth=self.params.max_depth,
-                                    min_depth=self.params.min_depth, mediums=self._mediums)
+                                    min_depth=self.params.min_depth, mediums=self._mediums, spectrum=self._spectrum)
         self.params = self.host_scene.params_copy()
         self.backend.set_render_params(self.params)
         self.invalidate()
