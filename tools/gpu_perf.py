@@ -8,7 +8,8 @@ from vision_amd.pipeline import Pipeline
 
 scene = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "scenes/classroom/vision_scene.json")
 w, h, spp, reps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 2
-pipe = Pipeline(scene, width=w, height=h)
+spectrum = os.environ.get("VMK_SPECTRUM") or None  # "hero" / "srgb" override of the scene's spectrum block
+pipe = Pipeline(scene, width=w, height=h, spectrum=spectrum)
 t0 = time.time(); pipe.prepare(); print("prepare", time.time() - t0, "s accel", pipe.accel_info)
 for r in range(reps):
     pipe.invalidate(); pipe.backend.reset_counters()
