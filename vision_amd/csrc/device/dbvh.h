@@ -37,7 +37,7 @@ constexpr int kQuadXor3 = 0x1B; // quad_perm:[3,2,1,0]
 VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, V3 d, float *t_out, float *u_out, float *v_out, uint32_t *inst_out, uint32_t *prim_out) {
     // 48 B record as three 16 B loads
     const float4 *q = reinterpret_cast<const float4 *>(tp);
-    float4 a = q[0], b = q[1], c = q[2];
+    float4 a = ldg(q), b = ldg(q + 1), c = ldg(q + 2);
     V3 p0 = {a.x, a.y, a.z}, p1 = {a.w, b.x, b.y}, p2 = {b.z, b.w, c.x};
     *inst_out = f2u(c.y); *prim_out = f2u(c.z);
     V3 e1 = p1 - p0, e2 = p2 - p0;
@@ -173,8 +173,8 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 if (__any(waiting)) break;
             }
             if (at_node) { // lane q tests child q
-                const float4 *p = reinterpret_cast<const float4 *>(S.nodes + cur) + q * 2u;
-                float4 a = p[0], b = p[1];
+                const uint32_t off = (uint32_t) cur * (uint32_t) sizeof(BvhNode) + q * 32u; // < 4 GiB: vmk_build_accel checks
+                float4 a = ldg_off(S.nodes, off), b = ldg_off(S.nodes, off + 16u);
                 int32_t ref = (int32_t) f2u(b.z);
                 float tn;
                 // (unused slots hold a far-away point box; the explicit ref test keeps NaN rays, whose slab test passes

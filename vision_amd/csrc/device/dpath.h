@@ -83,17 +83,18 @@ VD float remapping(float a, float low, float high) { return (a - low) / (high - 
 VD V4 fetch_texel(const uint8_t *base, uint32_t format, uint32_t width, const float *srgb_lut, int x, int y) {
     size_t i = (size_t) y * width + (size_t) x;
     if (format == VMK_TEX_RGBA32F) {
-        float4 p = *reinterpret_cast<const float4 *>(base + i * 16);
+        float4 p = ldg(reinterpret_cast<const float4 *>(base + i * 16));
         return {p.x, p.y, p.z, p.w};
     }
-    uint32_t p = *reinterpret_cast<const uint32_t *>(base + i * 4);
+    uint32_t p = ldg(reinterpret_cast<const uint32_t *>(base + i * 4));
     uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu, a = p >> 24;
-    if (format == VMK_TEX_RGBA8_SRGB) return {srgb_lut[r], srgb_lut[g], srgb_lut[b], (float) a * (1.f / 255.f)};
+    if (format == VMK_TEX_RGBA8_SRGB) return {ldg(srgb_lut + r), ldg(srgb_lut + g), ldg(srgb_lut + b), (float) a * (1.f / 255.f)};
     return {(float) r * (1.f / 255.f), (float) g * (1.f / 255.f), (float) b * (1.f / 255.f), (float) a * (1.f / 255.f)};
 }
 VD int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 __device__ __noinline__ float4 sample_image_ool(const vmk_texture *textures, const uint8_t *tex_data, const float *srgb_lut, uint32_t tex_id, float u, float v) {
-    const vmk_texture t = textures[tex_id];
+    vmk_texture t; // (the pointers are generic inside this out-of-line routine: say where they point)
+    t.offset = ldg(&textures[tex_id].offset); t.width = ldg(&textures[tex_id].width); t.height = ldg(&textures[tex_id].height); t.format = ldg(&textures[tex_id].format);
     const uint8_t *base = tex_data + t.offset;
     float x = u * (float) t.width - 0.5f, y = v * (float) t.height - 0.5f;
     float fx0 = floor_(x), fy0 = floor_(y);
@@ -121,8 +122,8 @@ VD void sample_lut2d(const float *lut, float u, float v, float *out) {
     int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        float c00 = lut[(y0 * N + x0) * NC + c], c10 = lut[(y0 * N + x1) * NC + c];
-        float c01 = lut[(y1 * N + x0) * NC + c], c11 = lut[(y1 * N + x1) * NC + c];
+        float c00 = ldg(lut + (y0 * N + x0) * NC + c), c10 = ldg(lut + (y0 * N + x1) * NC + c);
+        float c01 = ldg(lut + (y1 * N + x0) * NC + c), c11 = ldg(lut + (y1 * N + x1) * NC + c);
         out[c] = lerp_(ty, lerp_(tx, c00, c10), lerp_(tx, c01, c11));
     }
 }
@@ -137,10 +138,10 @@ VD void sample_lut3d(const float *lut, V3 uvw, float *out) {
     int z0 = clampi((int) fz0, 0, N - 1), z1 = clampi((int) fz0 + 1, 0, N - 1);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        float v000 = lut[((z0 * N + y0) * N + x0) * NC + c], v100 = lut[((z0 * N + y0) * N + x1) * NC + c];
-        float v010 = lut[((z0 * N + y1) * N + x0) * NC + c], v110 = lut[((z0 * N + y1) * N + x1) * NC + c];
-        float v001 = lut[((z1 * N + y0) * N + x0) * NC + c], v101 = lut[((z1 * N + y0) * N + x1) * NC + c];
-        float v011 = lut[((z1 * N + y1) * N + x0) * NC + c], v111 = lut[((z1 * N + y1) * N + x1) * NC + c];
+        float v000 = ldg(lut + ((z0 * N + y0) * N + x0) * NC + c), v100 = ldg(lut + ((z0 * N + y0) * N + x1) * NC + c);
+        float v010 = ldg(lut + ((z0 * N + y1) * N + x0) * NC + c), v110 = ldg(lut + ((z0 * N + y1) * N + x1) * NC + c);
+        float v001 = ldg(lut + ((z1 * N + y0) * N + x0) * NC + c), v101 = ldg(lut + ((z1 * N + y0) * N + x1) * NC + c);
+        float v011 = ldg(lut + ((z1 * N + y1) * N + x0) * NC + c), v111 = ldg(lut + ((z1 * N + y1) * N + x1) * NC + c);
         float a = lerp_(ty, lerp_(tx, v000, v100), lerp_(tx, v010, v110));
         float b = lerp_(ty, lerp_(tx, v001, v101), lerp_(tx, v011, v111));
         out[c] = lerp_(tz, a, b);
@@ -211,7 +212,7 @@ __device__ __noinline__ void rgb2spec_fetch_ool(const float *table, uint32_t max
     int x0 = clampi((int) fx0, 0, N - 1), x1 = clampi((int) fx0 + 1, 0, N - 1);
     int y0 = clampi((int) fy0, 0, N - 1), y1 = clampi((int) fy0 + 1, 0, N - 1);
     int z0 = clampi((int) fz0, 0, N - 1), z1 = clampi((int) fz0 + 1, 0, N - 1);
-    auto at = [&](int xi, int yi, int zi) { float4 v = t[((size_t) zi * N + yi) * N + xi]; return V3{v.x, v.y, v.z}; };
+    auto at = [&](int xi, int yi, int zi) { float4 v = ldg(t + ((size_t) zi * N + yi) * N + xi); return V3{v.x, v.y, v.z}; };
     V3 a = lerp3(ty, lerp3(tx, at(x0, y0, z0), at(x1, y0, z0)), lerp3(tx, at(x0, y1, z0), at(x1, y1, z0)));
     V3 b = lerp3(ty, lerp3(tx, at(x0, y0, z1), at(x1, y0, z1)), lerp3(tx, at(x0, y1, z1), at(x1, y1, z1)));
     *out = lerp3(tz, a, b);
@@ -536,8 +537,11 @@ VD float dielectric_refl_prob(const Lobe &l, V3 F) { // lobe.cpp:315-319
     V3 total = T * l.kr + F;
     return average(F) / average(total);
 }
-VD float dielectric_lut_x(const DScene &S, const Lobe &l, V3 wo, float eta) { // lobe.cpp:263-285
-    const float *lut = eta > 1.f ? S.lut_dielectric : S.lut_dielectric_inv;
+// The albedo tables the lobe code reads.  The out-of-line lobe routine gets these three pointers instead of the scene view,
+// so that no pointer to the view escapes the kernel: the view then lives in scalar registers, not in a per-lane scratch copy.
+struct LobeLuts { const float *pure_reflection, *dielectric, *dielectric_inv; };
+VD float dielectric_lut_x(const LobeLuts &S, const Lobe &l, V3 wo, float eta) { // lobe.cpp:263-285
+    const float *lut = eta > 1.f ? S.dielectric : S.dielectric_inv;
     float x = sqrt_(sqrt_(l.ax * l.ay));
     float y = abs_cos_theta(wo);
     float z = eta > 1.f ? inverse_lerp(eta, 1.003f, 5.f) : inverse_lerp(rcp(eta), 1.003f, 5.f);
@@ -551,7 +555,7 @@ VD V3 blend_f_specular(const Lobe &l, V3 wo, V3 wi, V3 wh) { // FresnelBlend::f_
 }
 
 // Lobe::evaluate_local_impl of every lobe class (local frame, before the |cos_i| factor)
-VD ScatterEval eval_local(const DScene &S, const Lobe &l, V3 wo, V3 wi, float *eta_out) {
+VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float *eta_out) {
     ScatterEval se; se.f = mk3(0.f); se.pdf = 0.f; se.flags = flag::Unset;
     switch (l.kind) {
         case LB_LAMBERT: case LB_OREN_NAYAR: { // bxdf.cpp:34-46, bxdf.h:92-95, bxdf.cpp:103-121
@@ -584,7 +588,7 @@ VD ScatterEval eval_local(const DScene &S, const Lobe &l, V3 wo, V3 wi, float *e
             se.flags = flag::GlossyRefl;
             if (l.compensate) {
                 float alpha = sqrt_(l.ax * l.ay);
-                float v; sample_lut2d<1>(S.lut_pure_reflection, alpha, cos_theta(wo), &v);
+                float v; sample_lut2d<1>(S.pure_reflection, alpha, cos_theta(wo), &v);
                 se.f *= 1.f / v;
             }
             break;
@@ -718,16 +722,22 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
 // Out-of-line instances of the two big lobe routines.  Inlined into the 2-pass evaluate/sample loop they cost ~170 live
 // VGPRs (LICM hoists every wo-only term of every lobe kind out of the loop); as real calls the lobe code is compiled
 // once at <= 71 VGPRs and the megakernel fits 128 VGPRs (4 waves/SIMD) with far fewer spills.
-__device__ __noinline__ void eval_local_ool(const DScene *S, const Lobe *l, float wox, float woy, float woz, float wix, float wiy, float wiz,
-                                            float *eta, ScatterEval *out) {
-    *out = eval_local(*S, *l, mk3(wox, woy, woz), mk3(wix, wiy, wiz), eta);
+// (Variations tried and dropped.  Passing the lobe by value — as a struct, or as 20 scalar register arguments with the
+// results returned in registers, which removes every memory access from the call: with either, the single-lobe megakernel
+// variants disagreed with the unit kernel on 42 % of cbox_matte's pixels (vmk_self_check caught it; the unit kernel still
+// matched the oracle) and the struct form ran 25 % slower.  Reading the lobe / writing the results through
+// address_space(5) casts of these pointers, to get scratch_load instead of flat_load in the callee: the media variant
+// faulted on the GPU.  The table pointers, on the other hand, are read with ldg() — global memory — inside the routine.)
+__device__ __noinline__ void eval_local_ool(const float *lut_pure_reflection, const float *lut_dielectric, const float *lut_dielectric_inv, const Lobe *l,
+                                            float wox, float woy, float woz, float wix, float wiy, float wiz, float *eta, ScatterEval *out) {
+    *out = eval_local(LobeLuts{lut_pure_reflection, lut_dielectric, lut_dielectric_inv}, *l, mk3(wox, woy, woz), mk3(wix, wiy, wiz), eta);
 }
 __device__ __noinline__ void sample_wi_local_ool(const Lobe *l, float wox, float woy, float woz, Sampler *sampler, V3 *wi, bool *valid) {
     *wi = sample_wi_local(*l, mk3(wox, woy, woz), *sampler, valid);
 }
 VD ScatterEval eval_local_call(const DScene &S, const Lobe &l, V3 wo, V3 wi, float *eta) {
     ScatterEval se;
-    eval_local_ool(&S, &l, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z, eta, &se);
+    eval_local_ool(S.lut_pure_reflection, S.lut_dielectric, S.lut_dielectric_inv, &l, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z, eta, &se);
     return se;
 }
 VD V3 sample_wi_local_call(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {

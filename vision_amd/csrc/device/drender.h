@@ -199,8 +199,12 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
 // planes into the accumulation buffer in frame order (the film's running mean is order dependent).  Path-granular
 // items keep every lane busy to the end of the launch however few pixels a GPU owns (1/8 of the image at 8 GPUs is
 // fewer pixels than resident lanes) and whatever the cost spread between pixels.
-struct RenderArgs {
-    const DScene *scene;
+// The scene view travels BY VALUE in the kernel arguments: its fields are then scalar loads from the kernarg segment, and
+// the compiler knows its pointers are global-memory addresses (pointers inside a kernel-argument struct are coerced to the
+// global address space; loaded from a DScene in memory they would be generic and every access a flat_load with 64-bit
+// VALU address arithmetic, counted on lgkmcnt as well as vmcnt).  Measured on classroom: 2270 -> 2530 Mrays/s together with
+// keeping the view out of scratch (see LobeLuts in dpath.h).
+struct RenderRest {
     const vmk_render_params *params;
     float4 *accum;
     float4 *stage;        // [frame_count][n_slots]
@@ -210,6 +214,7 @@ struct RenderArgs {
     uint32_t tile_size, tile_shift, tiles_x, tiles_y, rank, world;
     uint32_t n_slots, n_items, chunk; // chunk: items a wave claims with one atomic
 };
+struct RenderArgs : RenderRest { DScene scene; };
 
 __device__ __forceinline__ uint32_t compact_bits(uint32_t v) { // inverse of 2-D Morton interleave (even bits)
     v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; v = (v | (v >> 8)) & 0x0000FFFFu;
@@ -221,7 +226,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ bool slot_to_pixel(const RenderArgs &A, uint32_t slot, uint32_t width, uint32_t height, uint32_t *px, uint32_t *py) {
+__device__ __forceinline__ bool slot_to_pixel(const RenderRest &A, uint32_t slot, uint32_t width, uint32_t height, uint32_t *px, uint32_t *py) {
     uint32_t k = slot >> (2u * A.tile_shift), r = slot & (A.tile_size * A.tile_size - 1u);
     uint32_t tile = A.rank + k * A.world;
     uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
@@ -235,7 +240,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderArgs &A, uint32_t slot
 template<bool FULL, bool MEDIA>
 __global__ __launch_bounds__(kBlock, (MEDIA || VMK_HERO) ? 4 : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
-    const DScene S = *A.scene;
+    const DScene S = A.scene;
     const vmk_render_params *P = A.params;
     const uint32_t lane = threadIdx.x & 63u;
     WaveScratch *ws = s_ws + (threadIdx.x >> 6);

@@ -60,6 +60,20 @@ using DScene = DSceneFull;
 using DScene = DSceneBase;
 #endif
 
+// Every pointer of the scene view comes out of memory, so the compiler has to treat it as a generic ("flat") address:
+// flat_load with 64-bit VALU address arithmetic, counted on both vmcnt and lgkmcnt (it then serialises against the LDS
+// traffic of the traversal).  They all point into hipMalloc'ed global memory; ldg() says so at the access.
+template<typename T>
+VD T ldg(const T *p) { return *(const __attribute__((address_space(1))) T *) p; } // scalars
+typedef float f4v __attribute__((ext_vector_type(4)));
+VD float4 ldg(const float4 *p) { f4v v = *(const __attribute__((address_space(1))) f4v *) p; return make_float4(v.x, v.y, v.z, v.w); }
+// 16 B at base + a 32-bit byte offset: the shape the global_load "scalar base + 32-bit VGPR offset" form wants
+VD float4 ldg_off(const void *base, uint32_t byte_off) {
+    const __attribute__((address_space(1))) char *b = (const __attribute__((address_space(1))) char *) base;
+    f4v v = *(const __attribute__((address_space(1))) f4v *) (b + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct DCounters { // per-lane tallies, wave-reduced into vmk_counters at kernel end
     uint32_t closest, shadow, nodes, tris, paths, hits, tex;
 };

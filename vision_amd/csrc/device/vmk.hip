@@ -25,7 +25,7 @@ using namespace vmkd;
 
 // the hero-spectrum instance of the megakernel lives in vmk_hero.hip
 hipError_t vmk_hero_occupancy(bool full, bool media, int *blocks_per_cu);
-hipError_t vmk_hero_launch_render(bool full, bool media, unsigned blocks, hipStream_t stream, const void *args, size_t args_bytes);
+hipError_t vmk_hero_launch_render(bool full, bool media, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -209,7 +209,7 @@ __global__ void k_bvh4_level(const Bvh4Work *in, int n_in, Bvh4Work *out_q, int 
 }
 
 // RGBFilm accumulation (frame_buffer.cpp:117-126): acc = lerp(1/(f+1), acc, L_f), frame by frame for every owned pixel
-__global__ void k_film_resolve(RenderArgs A) {
+__global__ void k_film_resolve(RenderRest A) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= A.n_slots) return;
     uint32_t px, py;
@@ -229,10 +229,9 @@ __global__ void k_film_resolve(RenderArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // traversal replay, tone map, unit tests
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_trace(const DScene *scene, uint32_t n, const float *org, const float *dir, const float *tmax,
+__global__ __launch_bounds__(kBlock) void k_trace(const DScene S, uint32_t n, const float *org, const float *dir, const float *tmax,
                                                   int any_hit, uint32_t *hit_out, unsigned long long *counters, uint32_t *queue, uint32_t chunk) {
     __shared__ WaveScratch s_ws[kBlock / 64];
-    const DScene S = *scene;
     WaveScratch *ws = s_ws + (threadIdx.x >> 6);
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
     // persistent waves: the quads of every wave pull rays from one pool (SoA planes, 4 B/lane loads) until it is empty
@@ -459,7 +458,7 @@ __global__ void k_albedo(uint32_t which, uint32_t res, uint32_t sample_num, floa
         case 3: l.fr.kind = FR_SCHLICK; l.fr.a = mk3(0.04f); l.fr.eta = schlick_ior_from_F0(pow4(rz)); break;
         default: l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 4.f); break;
     }
-    DScene none{}; // the lobes measured here never touch the scene (compensate == false)
+    LobeLuts none{}; // the lobes measured here never touch the scene (compensate == false)
     double acc0 = 0.0, acc1 = 0.0;
     for (uint32_t k = 0; k < sample_num; ++k) {
         bool valid = true;
@@ -822,6 +821,7 @@ int vmk_build_accel(vmk_ctx *ctx) {
     cleanup();
 #undef BUILD_TRY
     if (h_nodes > n_int) { ctx->error = "vmk_build_accel: BVH4 node count exceeds the allocation"; return VMK_ERR_STATE; }
+    if ((uint64_t) h_nodes * sizeof(BvhNode) > 0xffffffffull) { ctx->error = "vmk_build_accel: node array exceeds the 4 GiB the traversal's 32-bit node offsets address"; return VMK_ERR_UNSUPPORTED; }
     if (h_scalars[0] > kQuadStack) { ctx->error = "vmk_build_accel: worst-case traversal stack need " + std::to_string(h_scalars[0]) + " exceeds the per-ray LDS stack (" + std::to_string(kQuadStack) + ")"; return VMK_ERR_UNSUPPORTED; }
     DSceneFull &h = ctx->h_scene;
     h.tri_pos = ctx->tri_pos.p; h.tri_attr = ctx->tri_attr.p; h.tri_lookup = ctx->tri_lookup.p; h.nodes = ctx->nodes.p;
@@ -890,7 +890,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     if (kernel_ms) *kernel_ms = 0.f;
     if (frame_count == 0) return VMK_OK;
     RenderArgs A{};
-    A.scene = ctx->d_scene.p; A.params = ctx->d_params.p; A.accum = ctx->fb; A.queue = ctx->queue.p; A.counters = ctx->counters.p;
+    A.scene = ctx->h_scene; A.params = ctx->d_params.p; A.accum = ctx->fb; A.queue = ctx->queue.p; A.counters = ctx->counters.p;
     uint32_t ts = kDefaultTile, rank = 0, world = 1;
     if (tiles && tiles->tile_size) {
         ts = tiles->tile_size; rank = tiles->rank; world = tiles->world ? tiles->world : 1;
@@ -929,12 +929,12 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         uint64_t chunk = (n_items / ((uint64_t) grid * (kBlock / 64) * 8)) & ~63ull;
         A.chunk = (uint32_t) std::max<uint64_t>(64, std::min<uint64_t>(1024, chunk));
         HIP_TRY(hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream));
-        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, grid, ctx->stream, &A, sizeof(A)));
+        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
         else {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_film_resolve, dim3((A.n_slots + 255) / 256), dim3(256), 0, ctx->stream, A);
+        hipLaunchKernelGGL(k_film_resolve, dim3((A.n_slots + 255) / 256), dim3(256), 0, ctx->stream, static_cast<const RenderRest &>(A));
         HIP_TRY(hipGetLastError());
     }
     if (kernel_ms) {
@@ -1010,7 +1010,7 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     (void) hipEventRecord(ctx->ev0, ctx->stream);
     for (uint32_t r = 0; r < repeats; ++r) {
         (void) hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream);
-        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->d_scene.p, n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
+        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, static_cast<const DScene &>(ctx->h_scene), n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
     }
     (void) hipEventRecord(ctx->ev1, ctx->stream);
     e = hipMemcpyAsync(hit_out, h.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream);
