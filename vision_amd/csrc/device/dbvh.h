@@ -27,6 +27,13 @@ struct WaveScratch {
     uint32_t list[64];              // lanes with an active ray, compacted
 };
 
+// While a vertex is shaded no traversal is in flight and the wave's scratch is idle: the material code parks the lobe it
+// hands to the out-of-line lobe routines there (dpath.h stage_lobe).  This lane's slot, as a byte offset in LDS.
+static_assert(sizeof(WaveScratch) >= kLobeLdsDwords * 64u * 4u, "the parked lobe must fit the wave's traversal scratch");
+VD uint32_t lobe_lds_slot(WaveScratch *ws) {
+    return (uint32_t) (uintptr_t) (VMK_AS3 WaveScratch *) ws + (threadIdx.x & 63u) * 4u;
+}
+
 // DPP quad permutes (full rate, no LDS traffic).  Every use sits in quad-uniform control flow.
 template<int CTRL> VD int32_t quad_perm_i(int32_t v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
 template<int CTRL> VD float quad_perm_f(float v) { return u2f((uint32_t) __builtin_amdgcn_mov_dpp((int32_t) f2u(v), CTRL, 0xf, 0xf, true)); }

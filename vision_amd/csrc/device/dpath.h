@@ -728,21 +728,54 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
 // matched the oracle) and the struct form ran 25 % slower.  Reading the lobe / writing the results through
 // address_space(5) casts of these pointers, to get scratch_load instead of flat_load in the callee: the media variant
 // faulted on the GPU.  The table pointers, on the other hand, are read with ldg() — global memory — inside the routine.)
-__device__ __noinline__ void eval_local_ool(const float *lut_pure_reflection, const float *lut_dielectric, const float *lut_dielectric_inv, const Lobe *l,
+// The lobe itself crosses the call through LDS: the wave's traversal scratch (dbvh.h WaveScratch) is idle while a vertex is
+// shaded, so the caller parks the 20 dwords of the lobe there ([field][lane], one ds_write each) and the callee reads them
+// with ds_read — instead of 20 scratch stores in the caller and 20 flat loads (64-bit address arithmetic, HBM-backed,
+// counted on vmcnt and lgkmcnt) at the top of the callee, three times per vertex.  `lds` is the lane's byte offset in LDS.
+constexpr uint32_t kLobeLdsDwords = 20; // x 64 lanes x 4 B = 5 KiB <= sizeof(WaveScratch)
+#define VMK_AS3 __attribute__((address_space(3)))
+VD void stage_lobe(uint32_t lds, const Lobe &l) {
+    VMK_AS3 uint32_t *p = reinterpret_cast<VMK_AS3 uint32_t *>(lds);
+    uint32_t bits = l.compensate ? 1u : 0u;
+#if VMK_HERO
+    bits |= l.fr.eta_sp ? 2u : 0u;
+#endif
+    const uint32_t w[kLobeLdsDwords] = {(uint32_t) l.kind, f2u(l.kr.x), f2u(l.kr.y), f2u(l.kr.z), f2u(l.rs.x), f2u(l.rs.y), f2u(l.rs.z), f2u(l.A), f2u(l.B), f2u(l.ax), f2u(l.ay),
+                                        (uint32_t) l.fr.kind, f2u(l.fr.a.x), f2u(l.fr.a.y), f2u(l.fr.a.z), f2u(l.fr.b.x), f2u(l.fr.b.y), f2u(l.fr.b.z), f2u(l.fr.eta), bits};
+#pragma unroll
+    for (uint32_t k = 0; k < kLobeLdsDwords; ++k) p[k * 64u] = w[k];
+}
+VD Lobe staged_lobe(uint32_t lds) {
+    const VMK_AS3 uint32_t *p = reinterpret_cast<const VMK_AS3 uint32_t *>(lds);
+    uint32_t w[kLobeLdsDwords];
+#pragma unroll
+    for (uint32_t k = 0; k < kLobeLdsDwords; ++k) w[k] = p[k * 64u];
+    Lobe l;
+    l.kind = (int) w[0]; l.kr = mk3(u2f(w[1]), u2f(w[2]), u2f(w[3])); l.rs = mk3(u2f(w[4]), u2f(w[5]), u2f(w[6]));
+    l.A = u2f(w[7]); l.B = u2f(w[8]); l.ax = u2f(w[9]); l.ay = u2f(w[10]);
+    l.fr.kind = (int) w[11]; l.fr.a = mk3(u2f(w[12]), u2f(w[13]), u2f(w[14])); l.fr.b = mk3(u2f(w[15]), u2f(w[16]), u2f(w[17])); l.fr.eta = u2f(w[18]);
+    l.compensate = (w[19] & 1u) != 0u; l.weight = 1.f; l.sample_weight = 1.f; // (the weights are the caller's business)
+#if VMK_HERO
+    l.fr.eta_sp = (w[19] & 2u) != 0u;
+#endif
+    return l;
+}
+__device__ __noinline__ void eval_local_ool(const float *lut_pure_reflection, const float *lut_dielectric, const float *lut_dielectric_inv, uint32_t lobe_lds,
                                             float wox, float woy, float woz, float wix, float wiy, float wiz, float *eta, ScatterEval *out) {
-    *out = eval_local(LobeLuts{lut_pure_reflection, lut_dielectric, lut_dielectric_inv}, *l, mk3(wox, woy, woz), mk3(wix, wiy, wiz), eta);
+    *out = eval_local(LobeLuts{lut_pure_reflection, lut_dielectric, lut_dielectric_inv}, staged_lobe(lobe_lds), mk3(wox, woy, woz), mk3(wix, wiy, wiz), eta);
 }
-__device__ __noinline__ void sample_wi_local_ool(const Lobe *l, float wox, float woy, float woz, Sampler *sampler, V3 *wi, bool *valid) {
-    *wi = sample_wi_local(*l, mk3(wox, woy, woz), *sampler, valid);
+__device__ __noinline__ void sample_wi_local_ool(uint32_t lobe_lds, float wox, float woy, float woz, Sampler *sampler, V3 *wi, bool *valid) {
+    *wi = sample_wi_local(staged_lobe(lobe_lds), mk3(wox, woy, woz), *sampler, valid);
 }
-VD ScatterEval eval_local_call(const DScene &S, const Lobe &l, V3 wo, V3 wi, float *eta) {
+// (the lobe must have been parked with stage_lobe(lds, .) first)
+VD ScatterEval eval_local_call(const DScene &S, uint32_t lds, V3 wo, V3 wi, float *eta) {
     ScatterEval se;
-    eval_local_ool(S.lut_pure_reflection, S.lut_dielectric, S.lut_dielectric_inv, &l, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z, eta, &se);
+    eval_local_ool(S.lut_pure_reflection, S.lut_dielectric, S.lut_dielectric_inv, lds, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z, eta, &se);
     return se;
 }
-VD V3 sample_wi_local_call(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
+VD V3 sample_wi_local_call(uint32_t lds, V3 wo, Sampler &sampler, bool *valid) {
     V3 wi;
-    sample_wi_local_ool(&l, wo.x, wo.y, wo.z, &sampler, &wi, valid);
+    sample_wi_local_ool(lds, wo.x, wo.y, wo.z, &sampler, &wi, valid);
     return wi;
 }
 
@@ -855,6 +888,7 @@ struct MatCtx {
     int n;        // lobes
     bool is_set;  // LobeSet semantics (weights, valid_world_factor, 3 burnt draws)
     Lobe single;  // simple materials: the lobe itself
+    uint32_t lobe_lds; // this lane's slot in the wave's idle traversal scratch (byte offset in LDS), set by the caller of mat_prepare
     float mixw[2], mixsw[2]; // mix / add: lobe weights and sampling weights of the two children
     // principled
     int first;    // 0 with sheen, 1 without
@@ -1036,7 +1070,7 @@ template<bool FULL>
 VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Interaction &it, V3 world_wo, V3 world_wi, float *eta, DCounters &cnt SWL_P) {
     V3 wo = it.shading.to_local(world_wo), wi = it.shading.to_local(world_wi);
     if constexpr (!FULL) {
-        ScatterEval se = eval_local_call(S, mc.single, wo, wi, eta);
+        ScatterEval se = eval_local_call(S, mc.lobe_lds, wo, wi, eta); // (mat_evaluate_and_sample parked mc.single)
         se.f *= abs_cos_theta(wi);
         return se;
     }
@@ -1045,7 +1079,8 @@ VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Inter
 #pragma unroll 1
     for (int i = 0; i < mc.n; ++i) {
         Lobe l; mat_lobe<FULL>(S, mc, it, i, l, cnt SWL_A);
-        ScatterEval se = eval_local_call(S, l, wo, wi, eta);
+        stage_lobe(mc.lobe_lds, l);
+        ScatterEval se = eval_local_call(S, mc.lobe_lds, wo, wi, eta);
         se.f *= abs_cos_theta(wi);
         if (!mc.is_set) { ret = se; break; }
         float factor = l.kind == LB_DIELECTRIC ? 1.f : (sh_world ? 1.f : 0.f); // valid_world_factor lobe.cpp:35-38,373-375
@@ -1061,7 +1096,7 @@ VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Inter
 template<bool FULL>
 VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sampler &sampler, bool *valid, DCounters &cnt SWL_P) {
     V3 wo = it.shading.to_local(it.wo);
-    if constexpr (!FULL) return it.shading.to_world(sample_wi_local_call(mc.single, wo, sampler, valid));
+    if constexpr (!FULL) return it.shading.to_world(sample_wi_local_call(mc.lobe_lds, wo, sampler, valid));
     int strategy = 0;
     if (mc.is_set) {
         float uc = sampler.next_1d();
@@ -1077,7 +1112,8 @@ VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sa
         if (mc.n == 1) strategy = 0;
     }
     Lobe l; mat_lobe<FULL>(S, mc, it, strategy, l, cnt SWL_A);
-    V3 wi_local = sample_wi_local_call(l, wo, sampler, valid);
+    stage_lobe(mc.lobe_lds, l);
+    V3 wi_local = sample_wi_local_call(mc.lobe_lds, wo, sampler, valid);
     return it.shading.to_world(wi_local);
 }
 // MaterialEvaluator::evaluate (towards `wi_light`) followed by MaterialEvaluator::sample (material.cpp:132-184,
@@ -1086,6 +1122,7 @@ template<bool FULL>
 VD void mat_evaluate_and_sample(const DScene &S, const MatCtx &mc, const Interaction &it, V3 wi_light, Sampler &sampler,
                                 ScatterEval &se_light, BSDFSample &bs, DCounters &cnt SWL_P) {
     bs.eta = 1.f; bs.wi = mk3(0.f);
+    if constexpr (!FULL) stage_lobe(mc.lobe_lds, mc.single); // one lobe for all three calls
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         V3 wi = wi_light;

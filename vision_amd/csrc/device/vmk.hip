@@ -306,7 +306,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             it.uv = {a[10], a[11]};
             it.mat_id = mat_id; it.light_id = VMK_INVALID; it.prim_id = 0; it.prim_area = 1.f;
             V3 wi = normalize(mk3(a[7], a[8], a[9]));
-            MatCtx mc; mat_prepare<true>(S, S.materials + mat_id, it, mc, cnt);
+            MatCtx mc; mc.lobe_lds = lobe_lds_slot(s_ws); mat_prepare<true>(S, S.materials + mat_id, it, mc, cnt);
             Sampler smp; smp.start(f2u(a[1]), f2u(a[2]), f2u(a[3]), 1);
             ScatterEval se; BSDFSample bs;
             mat_evaluate_and_sample<true>(S, mc, it, wi, smp, se, bs, cnt);
