@@ -722,12 +722,13 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
 // Out-of-line instances of the two big lobe routines.  Inlined into the 2-pass evaluate/sample loop they cost ~170 live
 // VGPRs (LICM hoists every wo-only term of every lobe kind out of the loop); as real calls the lobe code is compiled
 // once at <= 71 VGPRs and the megakernel fits 128 VGPRs (4 waves/SIMD) with far fewer spills.
-// (Variations tried and dropped.  Passing the lobe by value — as a struct, or as 20 scalar register arguments with the
-// results returned in registers, which removes every memory access from the call: with either, the single-lobe megakernel
-// variants disagreed with the unit kernel on 42 % of cbox_matte's pixels (vmk_self_check caught it; the unit kernel still
-// matched the oracle) and the struct form ran 25 % slower.  Reading the lobe / writing the results through
-// address_space(5) casts of these pointers, to get scratch_load instead of flat_load in the callee: the media variant
-// faulted on the GPU.  The table pointers, on the other hand, are read with ldg() — global memory — inside the routine.)
+// (Variations tried and dropped: every form in which the RESULT of the evaluate routine does not come back through the
+// `ScatterEval *` out-pointer — the lobe and results by value as a struct, as 20 scalar register arguments with register
+// returns, or the results parked in LDS next to the lobe — made the single-lobe megakernel variants k_render<false, *>
+// deviate from the unit kernel and the oracle on 42 % of cbox_matte's pixels (deterministically, at 96 and 128 registers)
+// and fault on classroom, while the lobe-set variants and the unit kernel stayed exact; vmk_self_check caught each one.
+// No difference in the source semantics was found.  Reading the lobe through address_space(5) casts of a stack pointer
+// also faulted, in the media variant.  What is kept is what the parity tests hold exact.)
 // The lobe itself crosses the call through LDS: the wave's traversal scratch (dbvh.h WaveScratch) is idle while a vertex is
 // shaded, so the caller parks the 20 dwords of the lobe there ([field][lane], one ds_write each) and the callee reads them
 // with ds_read — instead of 20 scratch stores in the caller and 20 flat loads (64-bit address arithmetic, HBM-backed,
