@@ -216,6 +216,22 @@ def test_error_behaviour(backend):
         be.render_batch(0, 1)
     with pytest.raises(BackendError, match="bad argument"):
         be.test_eval(99, np.zeros((1, 4), np.float32), 8)
+    # tabulated-spectrum ("spd") slots and the uplift table belong to the hero spectrum: inconsistent tables are refused on the
+    # host, before anything reaches a kernel
+    from vision_amd.host import HostScene
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_hero.json"), width=16, height=16)
+    hs.scene.spectrum = 0   # claim sRGB while the metal / glass slots still reference spectra
+    with pytest.raises(BackendError, match="missing texture or spectrum"):
+        be.upload_scene(hs)
+    hs.scene.spectrum = 1
+    keep = hs.scene.spd_cie_count
+    hs.scene.spd_cie_count = 1 << 20   # CIE tables reaching past the spectra pool
+    with pytest.raises(BackendError, match="CIE tables out of range"):
+        be.upload_scene(hs)
+    hs.scene.spd_cie_count = keep
+    be.upload_scene(hs)      # the untouched tables are accepted
+    with pytest.raises(BackendError, match="sRGB instance"):
+        be.build_accel(); be.set_render_params(hs.params_copy()); be.render_aov(0)
     be.close()
 
 
