@@ -6,7 +6,9 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one megakernel batch: `--spp-per-step` consecutive 1-spp frames of the whole image (K steps accumulate
-K*spp samples per pixel; the default 16 x 64 is the metric's 1024 spp).  Scene tables and BVH are resident in HBM before
+K*spp samples per pixel; the default 4 x 256 is the metric's 1024 spp — the largest batch whose staging planes fit one
+launch at 1080p; the drain of the persistent kernel at the end of a launch costs ~2.5 ms whatever the batch, so larger
+batches lose less to it, most of all when 8 GPUs share the image).  Scene tables and BVH are resident in HBM before
 the timed region.  With N ranks the image tiles are sharded (weak per-pixel cost, strong over the image: the total
 work is fixed, so "scaling" is "strong") and every step ends with ONE all-reduce of the float4 framebuffer (RCCL).
 value = closest + shadow rays traced by all ranks in the timed steps / max-over-ranks wall time.
@@ -41,9 +43,9 @@ def algorithmic_bytes(c, pixels, launches, env_lit, texel_bytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "classroom", "vision_scene.json"))
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

@@ -2,7 +2,7 @@
 # rocprofv3 passes of the bench command (run on the GPU box from the repo root): kernel trace + stats, then three
 # separate --pmc passes (MI355X_MICROARCH.md §HBM: counters in their own runs).  Results under gpurun_out/prof/;
 # tools/summarize_profiles.py <tag> <spp> turns them into profiles/<tag>_*.   usage: tools/gpu_profile.sh [spp] [steps]
-SPP=${1:-64}; STEPS=${2:-2}
+SPP=${1:-256}; STEPS=${2:-2}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
