@@ -167,6 +167,11 @@ inline float eval_slot1(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
 // a2. spectrum — render_core/spectrum/{srgb,hero}.cpp, base/color/{spd,spectrum}.cpp.
 // A dimension-3 SampledSpectrum is a float3 in both modes.  In hero mode the path's SampledWavelengths live in a
 // thread-local (set by Li for the path being traced); every decode below reads them.
+// PARITY UNPINNED for the hero branch's data: Vision's sRGB->spectrum table (srgb2spec.h) is absent from the reference
+// checkout, so the table these functions read is regenerated by the host (vision_amd/csrc/host/rgb2spec_opt.h, the
+// published Jakob-Hanika fit) and pinned only by properties (round trip through the CIE observer, convergence of a hero
+// render to the sRGB render; tests/test_host.py, tests/test_oracle_render.py).  The arithmetic itself follows hero.cpp /
+// spd.cpp line by line, including SPD's 471/94 nm sample spacing.
 // =====================================================================================================
 struct Swl { float lambda[3]; float pdf[3]; };
 static thread_local Swl *tl_swl = nullptr; // non-null only while a hero-spectrum path is traced
