@@ -152,6 +152,27 @@ def test_config1_cbox_1024x1024_matches_oracle_on_sampled_tiles(backend):
     assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
 
 
+@pytest.mark.parametrize("scene, w, h, frames, kw", [
+    ("scenes/classroom/vision_scene.json", 1920, 1080, 2, {}),                 # hero <false, false> at the headline size
+    ("scenes/classroom/vision_scene.json", 960, 540, 2, {"mediums": True}),    # hero <false, true>: the scene's global fog
+    ("scenes/glass-of-water/vision_scene.json", 1024, 1024, 2, {}),            # config 4 "spectral glass" at its resolution
+])
+def test_hero_full_size_matches_oracle_on_sampled_tiles(backend, scene, w, h, frames, kw):
+    """The hero-spectrum instance of the megakernel (vmk_hero.hip) has no unit-kernel twin for vmk_self_check, so it gets the
+    full-size check directly: the GPU renders the whole image, the oracle every 64th 32x32 tile, bit for bit."""
+    from vision_amd import _abi
+    hs, p, osc, _ = _load(backend, scene, w, h, spectrum="hero", **kw)
+    assert hs.scene.spectrum == 1
+    backend.reset_accum(); backend.reset_counters()
+    backend.render_batch(0, frames)
+    img = backend.download_accum()
+    ref, cc = osc.render(p, 0, frames, tiles=_abi.Tiles(32, 7, 64))
+    owned = ref[..., 3] != 0.0
+    assert owned.sum() > 0 and cc["paths"] == owned.sum() * frames
+    assert np.array_equal(img[owned].view(np.uint32), ref[owned].view(np.uint32))
+    assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
+
+
 def test_glass_of_water_depth_64_parity(backend):
     """BASELINE config 4's integrator setting (max depth 64, min depth 3) on the glass-of-water scene in srgb mode."""
     hs, p, osc, _ = _load(backend, "scenes/glass-of-water/vision_scene.json", 96, 96, max_depth=64, min_depth=3)
