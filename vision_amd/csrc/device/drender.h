@@ -239,7 +239,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderRest &A, uint32_t slot
 // k_render<true, true> whose medium vertices differed from k_test's instance of the same path_bounce<true, true> and from
 // the oracle (caught by the cbox_media parity test; -O1, 4 waves, or removing the point-light branch all made it agree).
 template<bool FULL, bool MEDIA>
-__global__ __launch_bounds__(kBlock, (MEDIA || VMK_HERO) ? 4 : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, MEDIA ? 4 : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = A.scene;
     const vmk_render_params *P = A.params;
