@@ -1551,30 +1551,39 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         if (p.mis_mode == 1) return bounce == 0 ? weight : 0.f;
         return weight;
     };
-    for (uint32_t bounces = 0; bounces < p.max_depth; ++bounces) {
+    const float3 primary_dir = ray.d;
+    // mis_bsdf (integrator.cpp:175-232): trace, environment on a miss, medium sampling, pass-through, emitter on a hit.
+    // Returns 0 = the caller goes on with `it` (NEE + scattering), 1 = `$super_break`, 2 = `$super_continue`.
+    auto mis_bsdf = [&](uint32_t &bounces, bool inner, Interaction &it) -> int {
+        if (!inner && ray.d.x == primary_dir.x && ray.d.y == primary_dir.y && ray.d.z == primary_dir.z) return 1; // primary_miss :178-183 (before the trace is used)
         Hit hit = sv.trace_closest(ray);
         float *rec = (dbg && vtx < 8) ? dbg + 8 * vtx : nullptr;
         ++vtx;
         if (rec) { rec[0] = u2f(hit.inst); rec[1] = u2f(hit.prim); rec[2] = hit.bary.x; rec[3] = hit.bary.y; }
-        if (hit.is_miss()) { // evaluate_miss
+        if (hit.is_miss()) { // evaluate_miss :137-158
             if (s->env_light != VMK_INVALID) {
                 LightSampleContext p_ref{ray.o, prev_surface_ng};
+                float3 tr = make_float3(1.f);
+                if (p.process_mediums) { // :146-151: rs.ray.dir_max.w = world_diameter; tr = geometry.Tr(scene, swl, rs)
+                    ray.t_max = s->lights[s->env_light].world_diameter;
+                    tr = geometry_Tr(s, p, ray, ray_medium);
+                }
                 LightEval eval = light_evaluate_miss_wi(lc, p_ref, ray.d);
                 float weight = correct_bsdf_weight(MIS_weight(scatter_pdf, eval.pdf), bounces);
-                L += spec_linear_srgb(s, (eval.L * 1.f * weight) * T);
+                L += spec_linear_srgb(s, (eval.L * tr * weight) * T);
             }
-            break;
+            return 1;
         }
-        Interaction it = compute_surface_interaction(s, hit, ray);
+        it = compute_surface_interaction(s, hit, ray);
         if (p.process_mediums && ray_medium != VMK_INVALID) // integrator.cpp:199-206
             T *= medium_sample(s, s->mediums[ray_medium], ray_medium, ray, it, sampler);
         if (!it.has_material() && !it.has_phase()) { // integrator.cpp:208-214
             ray_medium = spawn_medium(p, it, ray.d);
             ray = spawn_ray(it.pos, it.ng, ray.d);
             bounces -= 1;
-            continue;
+            return 2;
         }
-        if (!it.has_phase()) tl_cnt.hits++;
+        if (!it.has_phase() && inner) tl_cnt.hits++; // (counter of shaded surface vertices: one per shadow ray)
         if (it.has_emission()) { // integrator.cpp:221-231
             LightSampleContext p_ref{ray.o, prev_surface_ng};
             LightEval eval = light_evaluate_hit_wi(lc, p_ref, it);
@@ -1583,6 +1592,14 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
             L += spec_linear_srgb(s, eval.L * T * weight * tr);
         }
         prev_surface_ng = it.ng;
+        return 0;
+    };
+    for (uint32_t bounces = 0; bounces < p.max_depth; ++bounces) {
+        Interaction it;
+        int st = mis_bsdf(bounces, true, it);
+        if (st == 1) break;
+        if (st == 2) continue;
+        float *rec = (dbg && vtx - 1 < 8) ? dbg + 8 * (vtx - 1) : nullptr;
         // NEE
         LightSampleContext lsc{it.pos, it.ng};
         LightSample ls = light_sample_wi(lc, lsc, sampler);
@@ -1629,6 +1646,12 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         scatter_pdf = bs.eval.pdf;
         ray_medium = spawn_medium(p, it, bs.wi);
         ray = spawn_ray(it.pos, it.ng, bs.wi);
+    }
+    if (p.max_depth < 2 && p.mis_mode == 0) { // integrator.cpp:302-307: `only_direct && mis_mode_ == EBoth` — the BSDF-sampling half of the direct-light MIS
+        for (uint32_t bounce = 0; bounce < 1u; ++bounce) {
+            Interaction it;
+            if (mis_bsdf(bounce, false, it) == 1) break;
+        }
     }
     return L;
 }

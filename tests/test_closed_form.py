@@ -1,0 +1,156 @@
+"""Closed-form pins: scenes whose radiance is known analytically, so the expected value does NOT come from this repo's
+oracle (the oracle and the device code share an author; a misreading of the reference shows up only against
+something independent).  Each case is checked on the CPU oracle (always) and on the GPU (-m gpu).
+
+1. Environment light seen through a global homogeneous medium (integrator.cpp:137-158, geometry.cpp:187-199,
+   homogeneous.cpp:33-48): a camera ray that leaves the scene inside a medium carries
+       L = L_env * exp(-sigma_t * min(RayTMax, |d| * world_diameter))
+   (`rs.ray.dir_max.w = world_diameter; tr = geometry.Tr(...)`), with |d| = 1 for camera rays and
+   world_diameter = 2 * max(aabb_radius, min_world_radius) (scene.h:108-109).
+2. The same scene without `mediums.process`: L = L_env exactly.
+3. A diffuse plane under a constant environment, max_depth = 1 (integrator.cpp:302-307, the `only_direct` supplement):
+   NEE + the BSDF-sampled half of the MIS pair must add up to the furnace value  albedo * L_env  per pixel in expectation.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+ENV_RGB = (0.8, 0.5, 0.25)
+ENV_SCALE = 2.0
+SIGMA_A = (0.010, 0.020, 0.040)
+SIGMA_S = (0.030, 0.010, 0.005)
+MED_SCALE = 1.5
+MIN_WORLD_RADIUS = 10.0
+
+
+def _scene(tmp_path, mediums, plane=False, max_depth=4):
+    """Camera at the origin looking down -z; one small quad (in its local xz plane) BEHIND the camera (never seen) so the geometry tables are
+    non-empty, or (plane=True) a large diffuse floor in front of it; a constant-colour spherical light; optional global fog."""
+    ident = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
+    quad_xf = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 5, 1]] if not plane else [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, -1, 0, 1]]
+    sc = {
+        "shapes": [{"type": "quad", "name": "q", "param": {"width": 0.5 if not plane else 4000.0, "height": 0.5 if not plane else 4000.0, "material": "grey",
+                                                         "transform": {"type": "matrix4x4", "param": {"matrix4x4": quad_xf}}}}],
+        "materials": [{"type": "diffuse", "name": "grey", "param": {"color": [0.6, 0.4, 0.2]}}],
+        "sampler": {"type": "independent", "param": {"spp": 1}},
+        "integrator": {"type": "pt", "param": {"max_depth": max_depth, "min_depth": 5, "rr_threshold": 1}},
+        "camera": {"type": "thin_lens", "param": {"fov_y": 60, "transform": {"type": "look_at", "param": {"position": [0, 0, 0], "up": [0, 1, 0], "target_pos": [0, -0.35 if plane else 0.0, -1]}},
+                                                  "filter": {"type": "box", "param": {"radius": 0.5}}}},
+        "light_sampler": {"type": "uniform", "param": {"lights": [{"type": "spherical", "param": {"color": list(ENV_RGB), "scale": ENV_SCALE,
+                                                                                                   "o2w": {"type": "Euler", "param": {"yaw": 0}}}}]}},
+        "spectrum": {"type": "srgb"},
+        "render_setting": {"min_world_radius": MIN_WORLD_RADIUS},
+        "pipeline": {"type": "fixed", "param": {"frame_buffer": {"type": "normal", "param": {"resolution": [24, 16], "exposure": 1, "tone_mapper": {"type": "linear"}}}}},
+        "output": {"fn": "x.png", "spp": 1},
+    }
+    if mediums is not None:
+        sc["mediums"] = {"global": "fog", "process": bool(mediums), "list": [{"type": "homogeneous", "name": "fog", "param": {"g": 0.3, "scale": MED_SCALE, "sigma_a": list(SIGMA_A), "sigma_s": list(SIGMA_S)}}]}
+    path = os.path.join(str(tmp_path), f"closed_{int(bool(mediums))}_{int(plane)}_{max_depth}.json")
+    json.dump(sc, open(path, "w"))
+    return path
+
+
+def _expected_fog():
+    """Analytic value: the quad's bounding box is 0.5 x 0.5 x 0, so aabb_radius < min_world_radius and world_diameter = 20."""
+    sigma_t = (np.array(SIGMA_A, np.float64) + np.array(SIGMA_S, np.float64)) * MED_SCALE
+    return np.array(ENV_RGB, np.float64) * ENV_SCALE * np.exp(-sigma_t * 2.0 * MIN_WORLD_RADIUS)
+
+
+def _check_uniform(img, expected, rtol):
+    rgb = img[..., :3].astype(np.float64)
+    assert np.isfinite(rgb).all()
+    err = np.abs(rgb / expected - 1.0).max()
+    assert err <= rtol, (err, rgb.reshape(-1, 3)[0], expected)
+
+
+def _render_oracle(path, mediums, spp=2, **kw):
+    from vision_amd.host import HostScene
+    from oracle import oracle_py
+    hs = HostScene(path, mediums=mediums, **kw)
+    img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
+    return hs, img, cnt
+
+
+def _render_gpu(path, mediums, spp=2, **kw):
+    from vision_amd.backend import Backend
+    from vision_amd.host import HostScene
+    hs = HostScene(path, mediums=mediums, **kw)
+    be = Backend(0)
+    try:
+        be.upload_scene(hs); be.build_accel(); be.set_render_params(hs.params_copy())
+        be.reset_accum(); be.reset_counters()
+        be.render_batch(0, spp)
+        return hs, be.download_accum(), be.counters()
+    finally:
+        be.close()
+
+
+# float32 path: exp_ is this build's polynomial exponential (<= 2 ulp), the product chain adds a few ulp more
+RTOL = 2e-6
+
+
+def test_env_through_global_fog_closed_form_oracle(built, tmp_path):
+    hs, img, cnt = _render_oracle(_scene(tmp_path, True), True)
+    assert hs.params.process_mediums and hs.params.camera_medium == 0
+    assert cnt["closest_rays"] == cnt["paths"] and cnt["shadow_rays"] == 0  # every camera ray escapes
+    _check_uniform(img, _expected_fog(), RTOL)
+    # and the attenuation is real: the un-attenuated value is ~2x larger in blue
+    assert (img[..., :3].reshape(-1, 3)[0] < np.array(ENV_RGB) * ENV_SCALE * 0.6).all()
+
+
+def test_env_without_medium_closed_form_oracle(built, tmp_path):
+    for mediums, path in ((False, _scene(tmp_path, False)), (False, _scene(tmp_path, None)), (False, _scene(tmp_path, True))):
+        hs, img, _ = _render_oracle(path, mediums)  # (third case: fog declared, vmk_host_options.mediums = 0 -> the non-fog variant)
+        assert not hs.params.process_mediums
+        _check_uniform(img, np.array(ENV_RGB, np.float64) * ENV_SCALE, 1e-6)
+
+
+def _furnace_expected():
+    return np.array([0.6, 0.4, 0.2]) * np.array(ENV_RGB) * ENV_SCALE
+
+
+def _check_furnace(img):
+    """Floor pixels (lower half of the image): E[L] = albedo * L_env for a Lambertian plane under a constant environment
+    with nothing else in the scene, at max_depth = 1: direct light only, so NEE-weighted + BSDF-weighted MIS halves sum to
+    the full estimator only if the supplement pass of integrator.cpp:302-307 is there.  Without it the mean drops by the
+    BSDF half's share (~50 % for a uniform light sampled by a cosine lobe vs. the map's own pdf)."""
+    rgb = img[..., :3].astype(np.float64)
+    floor = rgb[12:, :, :].reshape(-1, 3)
+    mean = floor.mean(0)
+    assert np.abs(mean / _furnace_expected() - 1.0).max() < 0.02, (mean, _furnace_expected())
+
+
+def test_direct_only_supplement_furnace_oracle(built, tmp_path):
+    hs, img, cnt = _render_oracle(_scene(tmp_path, None, plane=True, max_depth=1), False, spp=256)
+    assert hs.params.max_depth == 1 and hs.params.mis_mode == 0
+    _check_furnace(img)
+    # sky pixels see the environment directly
+    _check_uniform(img[:2], np.array(ENV_RGB, np.float64) * ENV_SCALE, 1e-6)
+
+
+@pytest.mark.gpu
+def test_env_through_global_fog_closed_form_gpu(built, tmp_path):
+    hs, img, cnt = _render_gpu(_scene(tmp_path, True), True)
+    assert cnt["closest_rays"] == cnt["paths"] and cnt["shadow_rays"] == 0
+    _check_uniform(img, _expected_fog(), RTOL)
+
+
+@pytest.mark.gpu
+def test_env_without_medium_closed_form_gpu(built, tmp_path):
+    hs, img, _ = _render_gpu(_scene(tmp_path, False), False)
+    _check_uniform(img, np.array(ENV_RGB, np.float64) * ENV_SCALE, 1e-6)
+
+
+@pytest.mark.gpu
+def test_direct_only_supplement_furnace_gpu(built, tmp_path):
+    path = _scene(tmp_path, None, plane=True, max_depth=1)
+    hs, img, cnt = _render_gpu(path, False, spp=256)
+    _check_furnace(img)
+    _, ref, co = _render_oracle(path, False, spp=256)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    for k in ("closest_rays", "shadow_rays", "paths", "surface_hits"):
+        assert cnt[k] == co[k], (k, cnt[k], co[k])

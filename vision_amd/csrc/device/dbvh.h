@@ -204,6 +204,12 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                     int slot = sp + (n - 1 - rank);
                     if (slot < kQuadStack) ws->stack[slot][quad] = (uint32_t) ref;
                 }
+                // The pops below read entries that OTHER lanes of the quad have just written.  The hardware keeps the LDS
+                // operations of a wave in issue order, so all that is needed is that every lane's store is ISSUED before
+                // any lane's load: a convergent fence between the two, which the compiler may neither duplicate into the
+                // divergent `if` above nor sink loads across (no instruction is emitted for it).  Without it the order of
+                // the two was a property of the block layout the optimiser happened to pick ("UB").
+                wave_lds_fence();
                 if (n > 0) { cur = cand; sp = min(sp + n - 1, kQuadStack); }
                 else VMK_POP();
                 if (cur < 0 && pend == kTravDone) { pend = cur; VMK_POP(); } // park the leaf, keep descending

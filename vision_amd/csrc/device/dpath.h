@@ -203,7 +203,7 @@ VD float sigmoid_polynomial(V3 c, float lambda) {
 VD float inverse_smooth_step(float x) { return 0.5f - sin_(asin_(1.0f - 2.0f * x) * (1.0f / 3.0f)); } // hero.cpp:66-68
 // RGBToSpectrumTable::decode_albedo, device variant (hero.cpp:142-171): the three 64^3 float4 textures, trilinear,
 // clamp addressing, texel centres at (i + 0.5) / res.  Kept out of line: ~10 call sites in the material code.
-__device__ __noinline__ void rgb2spec_fetch_ool(const float *table, uint32_t maxc, float cx, float cy, float cz, V3 *out) {
+__device__ __noinline__ V3 rgb2spec_fetch_ool(const float *table, uint32_t maxc, float cx, float cy, float cz) {
     const int N = (int) VMK_RGB2SPEC_RES;
     const float4 *t = reinterpret_cast<const float4 *>(table) + (size_t) maxc * N * N * N;
     float x = cx * (float) N - 0.5f, y = cy * (float) N - 0.5f, z = cz * (float) N - 0.5f;
@@ -215,7 +215,7 @@ __device__ __noinline__ void rgb2spec_fetch_ool(const float *table, uint32_t max
     auto at = [&](int xi, int yi, int zi) { float4 v = ldg(t + ((size_t) zi * N + yi) * N + xi); return V3{v.x, v.y, v.z}; };
     V3 a = lerp3(ty, lerp3(tx, at(x0, y0, z0), at(x1, y0, z0)), lerp3(tx, at(x0, y1, z0), at(x1, y1, z0)));
     V3 b = lerp3(ty, lerp3(tx, at(x0, y0, z1), at(x1, y0, z1)), lerp3(tx, at(x0, y1, z1), at(x1, y1, z1)));
-    *out = lerp3(tz, a, b);
+    return lerp3(tz, a, b);
 }
 VD V3 rgb2spec_albedo_coeffs(const DScene &S, V3 rgb_in) {
     V3 rgb = {clamp_(rgb_in.x, 0.f, 1.f), clamp_(rgb_in.y, 0.f, 1.f), clamp_(rgb_in.z, 0.f, 1.f)};
@@ -229,7 +229,7 @@ VD V3 rgb2spec_albedo_coeffs(const DScene &S, V3 rgb_in) {
         float zz = inverse_smooth_step(inverse_smooth_step(z));
         const float res = (float) VMK_RGB2SPEC_RES;
         const float sc = (res - 1.0f) / res, of = 0.5f / res;
-        rgb2spec_fetch_ool(S.hero.rgb2spec, maxc, fma_(x, sc, of), fma_(y, sc, of), fma_(zz, sc, of), &c);
+        c = rgb2spec_fetch_ool(S.hero.rgb2spec, maxc, fma_(x, sc, of), fma_(y, sc, of), fma_(zz, sc, of));
     }
     return c;
 }
@@ -722,13 +722,6 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
 // Out-of-line instances of the two big lobe routines.  Inlined into the 2-pass evaluate/sample loop they cost ~170 live
 // VGPRs (LICM hoists every wo-only term of every lobe kind out of the loop); as real calls the lobe code is compiled
 // once at <= 71 VGPRs and the megakernel fits 128 VGPRs (4 waves/SIMD) with far fewer spills.
-// (Variations tried and dropped: every form in which the RESULT of the evaluate routine does not come back through the
-// `ScatterEval *` out-pointer — the lobe and results by value as a struct, as 20 scalar register arguments with register
-// returns, or the results parked in LDS next to the lobe — made the single-lobe megakernel variants k_render<false, *>
-// deviate from the unit kernel and the oracle on 42 % of cbox_matte's pixels (deterministically, at 96 and 128 registers)
-// and fault on classroom, while the lobe-set variants and the unit kernel stayed exact; vmk_self_check caught each one.
-// No difference in the source semantics was found.  Reading the lobe through address_space(5) casts of a stack pointer
-// also faulted, in the media variant.  What is kept is what the parity tests hold exact.)
 // The lobe itself crosses the call through LDS: the wave's traversal scratch (dbvh.h WaveScratch) is idle while a vertex is
 // shaded, so the caller parks the 20 dwords of the lobe there ([field][lane], one ds_write each) and the callee reads them
 // with ds_read — instead of 20 scratch stores in the caller and 20 flat loads (64-bit address arithmetic, HBM-backed,
@@ -761,23 +754,36 @@ VD Lobe staged_lobe(uint32_t lds) {
 #endif
     return l;
 }
-__device__ __noinline__ void eval_local_ool(const float *lut_pure_reflection, const float *lut_dielectric, const float *lut_dielectric_inv, uint32_t lobe_lds,
-                                            float wox, float woy, float woz, float wix, float wiy, float wiz, float *eta, ScatterEval *out) {
-    *out = eval_local(LobeLuts{lut_pure_reflection, lut_dielectric, lut_dielectric_inv}, staged_lobe(lobe_lds), mk3(wox, woy, woz), mk3(wix, wiy, wiz), eta);
+// Results come back BY VALUE (6 and 5 dwords: VGPR returns under the AMDGPU calling convention), the sampler state goes
+// in and out by value too: no pointer into the caller's private frame crosses the call, so nothing of the caller's is
+// forced into scratch and no flat access to the stack aperture exists in these routines.
+struct EvalRet { ScatterEval se; float eta; };
+struct SampleRet { V3 wi; uint32_t sampler_state; uint32_t valid; };
+__device__ __noinline__ EvalRet eval_local_ool(const float *lut_pure_reflection, const float *lut_dielectric, const float *lut_dielectric_inv, uint32_t lobe_lds,
+                                               float wox, float woy, float woz, float wix, float wiy, float wiz) {
+    EvalRet r;
+    r.eta = 0.f; // 0 = "not a dielectric lobe: leave the caller's eta alone" (a dielectric writes eta' > 0, lobe.cpp:333)
+    r.se = eval_local(LobeLuts{lut_pure_reflection, lut_dielectric, lut_dielectric_inv}, staged_lobe(lobe_lds), mk3(wox, woy, woz), mk3(wix, wiy, wiz), &r.eta);
+    return r;
 }
-__device__ __noinline__ void sample_wi_local_ool(uint32_t lobe_lds, float wox, float woy, float woz, Sampler *sampler, V3 *wi, bool *valid) {
-    *wi = sample_wi_local(staged_lobe(lobe_lds), mk3(wox, woy, woz), *sampler, valid);
+__device__ __noinline__ SampleRet sample_wi_local_ool(uint32_t lobe_lds, float wox, float woy, float woz, uint32_t sampler_state) {
+    Sampler s; s.state = sampler_state;
+    bool valid;
+    SampleRet r;
+    r.wi = sample_wi_local(staged_lobe(lobe_lds), mk3(wox, woy, woz), s, &valid);
+    r.sampler_state = s.state; r.valid = valid ? 1u : 0u;
+    return r;
 }
 // (the lobe must have been parked with stage_lobe(lds, .) first)
 VD ScatterEval eval_local_call(const DScene &S, uint32_t lds, V3 wo, V3 wi, float *eta) {
-    ScatterEval se;
-    eval_local_ool(S.lut_pure_reflection, S.lut_dielectric, S.lut_dielectric_inv, lds, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z, eta, &se);
-    return se;
+    EvalRet r = eval_local_ool(S.lut_pure_reflection, S.lut_dielectric, S.lut_dielectric_inv, lds, wo.x, wo.y, wo.z, wi.x, wi.y, wi.z);
+    if (eta && r.eta != 0.f) *eta = r.eta;
+    return r.se;
 }
 VD V3 sample_wi_local_call(uint32_t lds, V3 wo, Sampler &sampler, bool *valid) {
-    V3 wi;
-    sample_wi_local_ool(lds, wo.x, wo.y, wo.z, &sampler, &wi, valid);
-    return wi;
+    SampleRet r = sample_wi_local_ool(lds, wo.x, wo.y, wo.z, sampler.state);
+    sampler.state = r.sampler_state; *valid = r.valid != 0u;
+    return r.wi;
 }
 
 VD void microfacet_alpha(const DScene &S, const vmk_material *m, int slot_r, int slot_a, V2 uv, float rmin, float *ax, float *ay, DCounters &cnt) {

@@ -11,6 +11,9 @@ constexpr int kBlock = 256;
 #define VMK_WAVES_PER_SIMD 5 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane); measured on classroom with the
                              // quad traversal: 3: 2015, 4: 2206, 5: 2297, 6: 1825, 8: 1487 Mrays/s
 #endif
+#ifndef VMK_MEDIA_WAVES_PER_SIMD
+#define VMK_MEDIA_WAVES_PER_SIMD 4
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // one path vertex: IlluminationIntegrator::Li loop body (base/integral/integrator.cpp:160-311), no media
@@ -60,17 +63,24 @@ VD V3 hg_sample(V3 wo, float g, Sampler &sampler, float *f_out) { // 2 draws
     return wi;
 }
 // One path vertex for every lane of the wave: ALL lanes call this convergently (the two traversals inside are
-// wave-cooperative), `active` says whether the lane carries a live path.  Returns true when the lane's path ends at this
-// vertex.  `dbg` (tests / ray capture only): 16 floats per vertex —
+// wave-cooperative), `active` says whether the lane carries a live path.  Returns kPathEnd when the lane's path ends at
+// this vertex, kPathGoOn when it continues, and kPathTail when the bounce loop has run to max_depth in a configuration
+// with the supplement of integrator.cpp:302-307 (`only_direct && mis_mode == EBoth`, i.e. max_depth < 2): the caller
+// compares the new ray's direction with the primary ray's (`primary_miss`, :178-183) and either ends the path or calls
+// again; a call with ps.bounces >= max_depth runs that supplement — mis_bsdf(bounce, inner = false): trace, add the
+// environment / emitter the BSDF sample reaches with its MIS weight, no next-event estimation, no further bounce.
+// `dbg` (tests / ray capture only): 16 floats per vertex —
 // [hit inst, prim, bary.xy | light pdf, bsdf pdf towards the light, sampled pdf, occluded | shadow ray o.xyz d.xyz t_max, traced].
+enum : int { kPathGoOn = 0, kPathEnd = 1, kPathTail = 2 };
 template<bool FULL, bool MEDIA>
-__device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_params *P, WaveScratch *ws, PathState &ps, Sampler &sampler,
-                                            DCounters &cnt, float *dbg, bool active) {
+__device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_params *P, WaveScratch *ws, PathState &ps, Sampler &sampler,
+                                           DCounters &cnt, float *dbg, bool active) {
     const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
 #if VMK_HERO
     Swl &swl = ps.swl;
 #endif
-    if (max_depth == 0) return true; // `$for(&bounces, 0, max_depth)` never runs (uniform: P is a kernel argument)
+    if (max_depth == 0) return kPathEnd; // `$for(&bounces, 0, max_depth)` never runs (uniform: P is a kernel argument)
+    const bool tail = ps.bounces >= max_depth; // the supplement pass (see above)
     Hit hit;
     if (active) cnt.closest++;
     bool found = traverse_wave(S, ps.ray, active, false, ws, hit, cnt);
@@ -81,10 +91,17 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
     Ray shadow_ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
     if (active && !found) { // evaluate_miss integrator.cpp:137-158
         if (S.env_light != VMK_INVALID) {
+            V3 tr = mk3(1.f);
+            if constexpr (MEDIA) { // :146-151: a ray that leaves the scene inside a medium is attenuated over world_diameter
+                if (P->process_mediums) {
+                    ps.ray.t_max = S.lights[S.env_light].world_diameter;
+                    tr = geometry_Tr(S, P, ps.ray, ps.medium SWL_A);
+                }
+            }
             LightEval ev = light_evaluate_miss_wi(S, P, ps.ray.o, ps.ray.d, cnt SWL_A);
             float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
             weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
-            ps.L += spec_linear_srgb(S, (ev.L * 1.f * weight) * ps.T SWL_A);
+            ps.L += spec_linear_srgb(S, (ev.L * tr * weight) * ps.T SWL_A);
         }
     }
     bool pass_through = false;
@@ -121,7 +138,7 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
             ps.ray = spawn_ray(it.pos, it.ng, ps.ray.d);
             pass_through = true;
         } else {
-            if (!has_phase) cnt.hits++;
+            if (!has_phase && !tail) cnt.hits++;
             if (it.light_id != VMK_INVALID) { // integrator.cpp:221-231
                 LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt SWL_A);
                 float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
@@ -131,16 +148,18 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
                 ps.L += spec_linear_srgb(S, ev.L * ps.T * weight * tr SWL_A);
             }
             ps.prev_ng = it.ng;
-            // NEE (3 draws) + shadow ray
-            ls = light_sample_wi(S, P, it.pos, sampler, cnt SWL_A);
-            shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
-            shade = true;
-            cnt.shadow++;
+            if (!tail) {
+                // NEE (3 draws) + shadow ray
+                ls = light_sample_wi(S, P, it.pos, sampler, cnt SWL_A);
+                shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
+                shade = true;
+                cnt.shadow++;
+            }
         }
     }
     Hit sh;
     bool occluded = traverse_wave(S, shadow_ray, shade, true, ws, sh, cnt);
-    if (!shade) return !pass_through;
+    if (!shade) return pass_through ? kPathGoOn : kPathEnd;
     V3 tr_shadow = mk3(1.f);
     if constexpr (MEDIA) tr_shadow = geometry_Tr(S, P, shadow_ray, P->process_mediums ? (dot(it.ng, shadow_ray.d) > 0.f ? med_out : med_in) : VMK_INVALID SWL_A);
     V3 wi = normalize(ls.p_light - it.pos);
@@ -176,19 +195,28 @@ __device__ __forceinline__ bool path_bounce(const DScene &S, const vmk_render_pa
     ps.L += spec_linear_srgb(S, ps.T * Ld * tr_shadow SWL_A);
     ps.eta_scale *= sqr(bs.eta);
     float lum = max_comp(ps.T);
-    if (!(bs.eval.pdf > 0.f) || lum == 0.f) return true;
+    if (!(bs.eval.pdf > 0.f) || lum == 0.f) return kPathEnd;
     ps.T *= bs.eval.f / bs.eval.pdf;
     if (ps.eta_scale * lum < P->rr_threshold && ps.bounces >= min_depth) { // integrator.cpp:292-299
         float q = fmin_(0.95f, lum);
         float rr = sampler.next_1d();
-        if (q < rr) return true;
+        if (q < rr) return kPathEnd;
         ps.T = ps.T / q;
     }
     ps.scatter_pdf = bs.eval.pdf;
     if constexpr (MEDIA) ps.medium = P->process_mediums ? (dot(it.ng, bs.wi) > 0.f ? med_out : med_in) : VMK_INVALID; // interaction.cpp:114-123
     ps.ray = spawn_ray(it.pos, it.ng, bs.wi);
     ++ps.bounces;
-    return ps.bounces >= max_depth;
+    if (ps.bounces < max_depth) return kPathGoOn;
+    return (max_depth < 2u && mis_mode == 0u) ? kPathTail : kPathEnd; // integrator.cpp:302 `only_direct && mis_mode_ == EBoth`
+}
+// `primary_miss` of the supplement pass (integrator.cpp:178-183): the pass is skipped when the ray it would trace still
+// has the primary ray's direction.  The primary direction is not kept in registers for this one cold use: it is
+// regenerated from the path's (pixel, frame) key, out of line (the call sits on a path only max_depth < 2 launches take).
+__device__ __noinline__ bool tail_is_primary(const vmk_render_params *P, uint32_t px, uint32_t py, uint32_t frame, V3 d) {
+    Sampler s; s.start(px, py, frame, 0);
+    Ray r = generate_ray(P, px, py, s);
+    return r.d.x == d.x && r.d.y == d.y && r.d.z == d.z;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -239,7 +267,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderRest &A, uint32_t slot
 // k_render<true, true> whose medium vertices differed from k_test's instance of the same path_bounce<true, true> and from
 // the oracle (caught by the cbox_media parity test; -O1, 4 waves, or removing the point-light branch all made it agree).
 template<bool FULL, bool MEDIA>
-__global__ __launch_bounds__(kBlock, MEDIA ? 4 : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = A.scene;
     const vmk_render_params *P = A.params;
@@ -298,7 +326,13 @@ __global__ __launch_bounds__(kBlock, MEDIA ? 4 : VMK_WAVES_PER_SIMD) void k_rend
 
         // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
         // (all lanes take part: the traversals inside are wave-cooperative; lanes without a path contribute no ray)
-        bool terminate = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
+        int state = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
+        if (state == kPathTail && has_path) { // max_depth < 2 only (uniform per launch)
+            uint32_t f = item / A.n_slots, px, py;
+            (void) slot_to_pixel(A, item - f * A.n_slots, P->width, P->height, &px, &py);
+            state = tail_is_primary(P, px, py, A.frame_begin + f, ps.ray.d) ? kPathEnd : kPathGoOn;
+        }
+        const bool terminate = state != kPathGoOn;
         if (has_path && terminate) {
             A.stage[item] = make_float4(ps.L.x, ps.L.y, ps.L.z, 1.f);
             has_path = false;

@@ -267,6 +267,9 @@ __global__ void k_tonemap(const float4 *accum, float4 *out, uint32_t n, float ex
     out[i] = make_float4(v[0], v[1], v[2], 1.f);
 }
 
+// The unit kernel steps a path until it ends, like k_render (which is bounded by max_depth and the scene's geometry only:
+// pass-through vertices are not counted as bounces); the cap is a safety net far above anything a real path reaches.
+constexpr int kUnitPathVertexCap = 1 << 16;
 __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
     __shared__ WaveScratch s_ws[1]; // launched with 64-thread blocks
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,11 +331,12 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             smp.start(px, py, frame, 1);
             path_begin(ps, P);
             bool alive = live;
-            for (int v = 0; v < 64 && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
+            for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
                 float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                bool end = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                int st = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
                 if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
-                if (end) alive = false;
+                if (st == kPathTail && alive) st = tail_is_primary(P, px, py, frame, ps.ray.d) ? kPathEnd : kPathGoOn;
+                if (st != kPathGoOn) alive = false;
             }
             if (live) { o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z; }
             break;
@@ -347,17 +351,18 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             path_begin(ps, P);
             int nv = 0;
             bool alive = live && P->max_depth > 0;
-            for (int v = 0; v < 64 && __any(alive); ++v) {
+            for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) {
                 float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 Ray r = ps.ray;
-                bool end = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                int st = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
                 if (alive && v < 24) {
                     float *q = o + 1 + v * 16;
                     q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = r.t_max; q[7] = 1.f;
                     for (int k = 0; k < 8; ++k) q[8 + k] = dbg[8 + k];
                     nv = v + 1;
                 }
-                if (end) alive = false;
+                if (st == kPathTail && alive) st = tail_is_primary(P, px, py, frame, ps.ray.d) ? kPathEnd : kPathGoOn;
+                if (st != kPathGoOn) alive = false;
             }
             if (live) o[0] = (float) nv;
             break;
