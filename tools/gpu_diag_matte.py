@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Diagnostic: frame 0 of cbox_matte 32x32 through the megakernel of the library VMK_LIB points at vs the CPU oracle;
+prints the mismatch count, the counters of both sides and saves both images (gpurun_out/diag_<tag>.npz)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vision_amd.backend import Backend
+from vision_amd.host import HostScene
+from oracle import oracle_py
+tag = os.path.basename(os.environ.get("VMK_LIB", "default")).replace(".so", "")
+scene = sys.argv[1] if len(sys.argv) > 1 else "scenes/cbox/cbox_matte.json"
+hs = HostScene(os.path.join(ROOT, scene), width=32, height=32)
+p = hs.params_copy()
+be = Backend(0)
+be.upload_scene(hs); be.build_accel(); be.set_render_params(p)
+be.reset_accum(); be.reset_counters()
+be.render_batch(0, 1)
+img = be.download_accum(); cg = be.counters()
+ref, co = oracle_py.OracleScene(hs).render(p, 0, 1)
+bad = (img[..., :3].view(np.uint32) != ref[..., :3].view(np.uint32)).any(-1)
+if os.environ.get("VMK_DIAG_KIND8"):
+    aw = img[..., 3].astype(np.int64)
+    gen, nv = aw // 100, aw % 100
+    pixq = np.stack([np.tile(np.arange(32), 32), np.repeat(np.arange(32), 32), np.zeros(1024)], 1).astype(np.uint32).view(np.float32)
+    o6 = oracle_py.OracleScene(hs).test_eval(p, 6, pixq, 67)
+    print(" generation histogram (all / bad):", np.bincount(gen.ravel(), minlength=4)[:6], np.bincount(gen[bad].ravel(), minlength=4)[:6])
+    print(" vertices gpu (all mean / bad mean):", nv.mean(), nv[bad].mean() if bad.any() else 0)
+    print(" bad rows by image row:", bad.sum(1))
+print(tag, scene, "mismatching pixels", int(bad.sum()), "of", bad.size)
+print(" gpu counters", {k: cg[k] for k in ("closest_rays", "shadow_rays", "paths", "surface_hits", "nodes_visited", "tris_tested")})
+print(" cpu counters", {k: co[k] for k in ("closest_rays", "shadow_rays", "paths", "surface_hits")})
+if bad.any():
+    ys, xs = np.nonzero(bad)
+    for y, x in list(zip(ys, xs))[:6]:
+        print("  px", x, y, "gpu", img[y, x, :3], "cpu", ref[y, x, :3])
+    r = img[bad][:, :3].sum(1) / np.maximum(ref[bad][:, :3].sum(1), 1e-20)
+    print("  ratio gpu/cpu over bad pixels: min %.4g median %.4g max %.4g; gpu==0: %d, cpu==0: %d" % (r.min(), np.median(r), r.max(), int((img[bad][:, :3].sum(1) == 0).sum()), int((ref[bad][:, :3].sum(1) == 0).sum())))
+if os.environ.get("VMK_DIAG_KIND8"):
+    be2 = be
+    yy, xx = np.mgrid[0:32, 0:32]
+    pix = np.stack([xx.ravel(), yy.ravel(), np.zeros(1024)], 1).astype(np.uint32).view(np.float32)
+    g8 = be2.test_eval(8, pix, 67)
+    g6 = be2.test_eval(6, pix, 67)
+    o6 = oracle_py.OracleScene(hs).test_eval(p, 6, pix, 67)
+    eq = lambda a, b: (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    print(" kind6 vs oracle equal:", bool(eq(g6, o6).all()), " kind8 vs oracle rows differing:", int((~eq(g8, o6).all(1)).sum()))
+    print(" kind8 L vs megakernel image equal rows:", int(eq(g8[:, 64:67], img.reshape(-1, 4)[:, :3]).all(1).sum()))
+    import ctypes as C
+    L = be._L
+    L.vmk_diag_download.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    dg = np.zeros((1024, 8, 16), np.float32)
+    assert L.vmk_diag_download(be._h, dg.ctypes.data_as(C.c_void_p), dg.size) == 0
+    # items of a 32x32 single-rank launch: item = tile-major Morton slot; map item -> pixel through the alpha trick is not needed:
+    # compare per pixel using the hit record of vertex 0 to find the permutation
+    key8 = {tuple(g8[i, 0:4].view(np.uint32)): i for i in range(1024)}
+    perm = np.array([key8.get(tuple(dg[j, 0, 0:4].view(np.uint32)), -1) for j in range(1024)])
+    print(" items matched to pixels by primary hit:", int((perm >= 0).sum()), "unique", len(set(perm[perm >= 0])))
+    g7 = be2.test_eval(7, pix, 1 + 16 * 24)
+    nshow = 0
+    firsts = {}
+    raybad = {}
+    for j in range(1024):
+        i = perm[j]
+        if i < 0: continue
+        nvert = int(g7[i, 0])
+        for v in range(min(7, nvert - 1)):
+            nxt = g7[i, 1 + (v + 1) * 16: 1 + (v + 1) * 16 + 6]   # unit kernel: closest ray of vertex v+1
+            mine = dg[j, v, 8:14]                                  # k_render: ps.ray after vertex v
+            if not eq(nxt, mine).all():
+                raybad[v] = raybad.get(v, 0) + 1
+                if nshow < 5:
+                    print("  item", j, "pixel", i % 32, i // 32, "ray after vertex", v, "differs:\n    k_render o,d", mine, "\n    unit     o,d", nxt, "\n    hit at v", dg[j, v, :2].view(np.uint32), "T.x", dg[j, v, 14])
+                    nshow += 1
+                break
+    print(" first vertex after which the spawned ray differs {vertex: count}:", dict(sorted(raybad.items())))
+    stale = total = 0
+    for j in range(1024):
+        i = perm[j]
+        if i < 0: continue
+        nvert = int(g7[i, 0])
+        for v in range(1, min(7, nvert - 1)):
+            if not eq(g7[i, 1 + (v + 1) * 16: 1 + (v + 1) * 16 + 6], dg[j, v, 8:14]).all():
+                total += 1
+                stale += int(dg[j, v, 11].view(np.uint32) == dg[j, v - 1, 11].view(np.uint32))  # d.x carried over from the previous ray
+                break
+    print(" wrong rays whose d.x equals the PREVIOUS ray's d.x bit for bit:", stale, "of", total)
+    nshow = 0
+    for j in range(1024):
+        i = perm[j]
+        if i < 0: continue
+        a = dg[j, :, :8].reshape(-1); b = g8[i, :64]
+        d = ~eq(a, b)
+        if d.any():
+            k = int(np.nonzero(d)[0][0])
+            firsts[(k // 8, k % 8)] = firsts.get((k // 8, k % 8), 0) + 1
+            if nshow < 4:
+                v = k // 8
+                print("  item", j, "pixel", i % 32, i // 32, "first diff vertex", v, "field", k % 8)
+                for vv in range(max(0, v - 1), min(8, v + 2)):
+                    print("    v%d krender" % vv, dg[j, vv, :2].view(np.uint32), dg[j, vv, 2:8], "shadow", dg[j, vv, 8:15], hex(int(dg[j, vv, 15:16].view(np.uint32)[0])))
+                    print("    v%d unit   " % vv, g8[i, vv * 8:vv * 8 + 2].view(np.uint32), g8[i, vv * 8 + 2:vv * 8 + 8])
+                nshow += 1
+    print(" first-difference histogram {(vertex, field): count}:", dict(sorted(firsts.items())))
+    names = ["inst", "prim", "bu", "bv", "ls_pdf", "se_pdf", "bs_pdf", "occl"]
+    shown = 0
+    for i in np.nonzero(~eq(g8, o6).all(1))[0]:
+        d = ~eq(g8[i], o6[i])
+        j = int(np.nonzero(d)[0][0])
+        print("  pixel", i % 32, i // 32, "first diff at float", j, "= vertex", j // 8, names[j % 8] if j < 64 else "L", "gpu", g8[i, j], "cpu", o6[i, j])
+        if shown < 3:
+            v = j // 8 if j < 64 else 0
+            print("    gpu vtx", g8[i, v * 8:(v + 1) * 8].view(np.uint32)[:2], g8[i, v * 8 + 2:(v + 1) * 8])
+            print("    cpu vtx", o6[i, v * 8:(v + 1) * 8].view(np.uint32)[:2], o6[i, v * 8 + 2:(v + 1) * 8])
+        shown += 1
+        if shown >= 12: break
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.savez(os.path.join(ROOT, "gpurun_out", f"diag_{tag}.npz"), gpu=img, cpu=ref)
+be.close()

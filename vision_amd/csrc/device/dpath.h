@@ -761,12 +761,18 @@ struct EvalRet { ScatterEval se; float eta; };
 struct SampleRet { V3 wi; uint32_t sampler_state; uint32_t valid; };
 __device__ __noinline__ EvalRet eval_local_ool(const float *lut_pure_reflection, const float *lut_dielectric, const float *lut_dielectric_inv, uint32_t lobe_lds,
                                                float wox, float woy, float woz, float wix, float wiy, float wiz) {
+#ifdef VMK_OOL_BARRIER
+    asm volatile("" ::: "memory");
+#endif
     EvalRet r;
     r.eta = 0.f; // 0 = "not a dielectric lobe: leave the caller's eta alone" (a dielectric writes eta' > 0, lobe.cpp:333)
     r.se = eval_local(LobeLuts{lut_pure_reflection, lut_dielectric, lut_dielectric_inv}, staged_lobe(lobe_lds), mk3(wox, woy, woz), mk3(wix, wiy, wiz), &r.eta);
     return r;
 }
 __device__ __noinline__ SampleRet sample_wi_local_ool(uint32_t lobe_lds, float wox, float woy, float woz, uint32_t sampler_state) {
+#ifdef VMK_OOL_BARRIER
+    asm volatile("" ::: "memory");
+#endif
     Sampler s; s.state = sampler_state;
     bool valid;
     SampleRet r;
@@ -1134,6 +1140,9 @@ VD void mat_evaluate_and_sample(const DScene &S, const MatCtx &mc, const Interac
     for (int pass = 0; pass < 2; ++pass) {
         V3 wi = wi_light;
         bool valid = true;
+#ifdef VMK_STAGE_EACH_CALL
+        if constexpr (!FULL) stage_lobe(mc.lobe_lds, mc.single);
+#endif
         if (pass == 1) { wi = mat_sample_wi<FULL>(S, mc, it, sampler, &valid, cnt SWL_A); bs.wi = wi; }
         ScatterEval e = mat_evaluate_world<FULL>(S, mc, it, it.wo, wi, pass == 1 ? &bs.eta : nullptr, cnt SWL_A);
         e.pdf *= valid ? 1.f : 0.f;

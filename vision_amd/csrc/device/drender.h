@@ -12,7 +12,7 @@ constexpr int kBlock = 256;
                              // quad traversal: 3: 2015, 4: 2206, 5: 2297, 6: 1825, 8: 1487 Mrays/s
 #endif
 #ifndef VMK_MEDIA_WAVES_PER_SIMD
-#define VMK_MEDIA_WAVES_PER_SIMD 4
+#define VMK_MEDIA_WAVES_PER_SIMD VMK_WAVES_PER_SIMD
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -242,6 +242,9 @@ struct RenderRest {
     uint32_t frame_begin, frame_count;
     uint32_t tile_size, tile_shift, tiles_x, tiles_y, rank, world;
     uint32_t n_slots, n_items, chunk; // chunk: items a wave claims with one atomic
+#ifdef VMK_DIAG
+    float *diag; // [n_items][8 vertices][16 floats]: the dbg record of path_bounce (diagnostic builds only)
+#endif
 };
 struct RenderArgs : RenderRest { DScene scene; };
 
@@ -263,9 +266,9 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderRest &A, uint32_t slot
     return *px < width && *py < height;
 }
 
-// The MEDIA variants get the 128-register budget of 4 waves per SIMD: at 5 (96 registers) hipcc 7.2 -O3 produced a
-// k_render<true, true> whose medium vertices differed from k_test's instance of the same path_bounce<true, true> and from
-// the oracle (caught by the cbox_media parity test; -O1, 4 waves, or removing the point-light branch all made it agree).
+// All four <FULL, MEDIA> variants run at the same waves/SIMD.  (Round 1 pinned the MEDIA variants to 4 after a
+// k_render<true, true> at 96 registers disagreed with the unit kernel; the cause turned out to be the SLP-vectoriser
+// miscompile described in DESIGN.md section 8, which the build now avoids with -fno-slp-vectorize.)
 template<bool FULL, bool MEDIA>
 __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
@@ -289,6 +292,9 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
     ps.swl.lambda = mk3(538.f); ps.swl.pdf = mk3(1.f);
 #endif
 
+#ifdef VMK_DIAG
+    uint32_t diag_gen = 0, diag_verts = 0; // paths this lane has finished / vertices of the current one, returned in the film's alpha
+#endif
     for (;;) {
         // ---- hand new paths to idle lanes: ballot + prefix inside the wave, one atomic per chunk ----
         const unsigned long long need_mask = __ballot(!has_path);
@@ -326,15 +332,34 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
 
         // ---- one bounce of IlluminationIntegrator::Li (integrator.cpp:160-311) ----
         // (all lanes take part: the traversals inside are wave-cooperative; lanes without a path contribute no ray)
+#ifdef VMK_DIAG
+        float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int state = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, dbg, has_path);
+        if (has_path && diag_verts < 8u && A.diag) {
+            float *q = A.diag + ((size_t) item * 8u + diag_verts) * 16u;
+            for (int k = 0; k < 16; ++k) q[k] = dbg[k];
+            q[8] = ps.ray.o.x; q[9] = ps.ray.o.y; q[10] = ps.ray.o.z; q[11] = ps.ray.d.x; q[12] = ps.ray.d.y; q[13] = ps.ray.d.z; q[14] = ps.T.x;
+            q[15] = u2f(sampler.state);
+        }
+#else
         int state = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
+#endif
         if (state == kPathTail && has_path) { // max_depth < 2 only (uniform per launch)
             uint32_t f = item / A.n_slots, px, py;
             (void) slot_to_pixel(A, item - f * A.n_slots, P->width, P->height, &px, &py);
             state = tail_is_primary(P, px, py, A.frame_begin + f, ps.ray.d) ? kPathEnd : kPathGoOn;
         }
         const bool terminate = state != kPathGoOn;
+#ifdef VMK_DIAG
+        if (has_path) ++diag_verts;
+#endif
         if (has_path && terminate) {
+#ifdef VMK_DIAG
+            A.stage[item] = make_float4(ps.L.x, ps.L.y, ps.L.z, (float) (diag_gen * 100u + diag_verts));
+            ++diag_gen; diag_verts = 0;
+#else
             A.stage[item] = make_float4(ps.L.x, ps.L.y, ps.L.z, 1.f);
+#endif
             has_path = false;
         }
     }

@@ -220,7 +220,11 @@ __global__ void k_film_resolve(RenderRest A) {
     for (uint32_t f = 0; f < A.frame_count; ++f) {
         float4 l = A.stage[(size_t) f * A.n_slots + slot];
         float a = 1.f / (float) (A.frame_begin + f + 1u);
+#ifdef VMK_DIAG
+        V4 val = {l.x, l.y, l.z, l.w};
+#else
         V4 val = {l.x, l.y, l.z, 1.f};
+#endif
         acc = lerp4(a, acc, val);
     }
     A.accum[(size_t) py * width + px] = make_float4(acc.x, acc.y, acc.z, acc.w);
@@ -274,7 +278,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
     __shared__ WaveScratch s_ws[1]; // launched with 64-thread blocks
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
-    if (!live && kind != 6 && kind != 7) return; // kinds 6/7 trace rays: every lane of the wave has to stay
+    if (!live && kind != 6 && kind != 7 && kind != 8) return; // kinds 6/7 trace rays: every lane of the wave has to stay
     const float *a = in + (size_t) (live ? i : 0) * in_stride;
     float *o = out + (size_t) (live ? i : 0) * out_stride;
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
@@ -341,6 +345,26 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             if (live) { o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z; }
             break;
         }
+#ifdef VMK_DIAG
+        case 8: { // diagnostic build only: kind 6 through path_bounce<false, false> (single-lobe, no media)
+            const DScene S = *scene;
+            uint32_t px = f2u(a[0]), py = f2u(a[1]), frame = f2u(a[2]);
+            Sampler smp; smp.start(px, py, frame, 0);
+            PathState ps; ps.ray = generate_ray(P, px, py, smp);
+            smp.start(px, py, frame, 1);
+            path_begin(ps, P);
+            bool alive = live;
+            for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) {
+                float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                int st = path_bounce<false, false>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
+                if (st == kPathTail && alive) st = tail_is_primary(P, px, py, frame, ps.ray.d) ? kPathEnd : kPathGoOn;
+                if (st != kPathGoOn) alive = false;
+            }
+            if (live) { o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z; }
+            break;
+        }
+#endif
         case 7: { // ray capture of one (pixel, frame) for the traversal replay: o[0] = vertex count, then 16 floats per
                   // vertex [closest ray o.xyz d.xyz t_max, 1 | shadow ray o.xyz d.xyz t_max, traced]; needs out_stride >= 1 + 16 * 24
             const DScene S = *scene;
@@ -548,6 +572,9 @@ struct vmk_ctx {
     float4 *fb{nullptr};
     DevBuf<uint32_t> queue;
     DevBuf<unsigned long long> counters;
+#ifdef VMK_DIAG
+    DevBuf<float> diag;
+#endif
 };
 
 static thread_local std::string g_null_error;
@@ -934,6 +961,11 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         uint64_t chunk = (n_items / ((uint64_t) grid * (kBlock / 64) * 8)) & ~63ull;
         A.chunk = (uint32_t) std::max<uint64_t>(64, std::min<uint64_t>(1024, chunk));
         HIP_TRY(hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream));
+#ifdef VMK_DIAG
+        HIP_TRY(ctx->diag.alloc((size_t) n_items * 128));
+        HIP_TRY(hipMemsetAsync(ctx->diag.p, 0, (size_t) n_items * 128 * 4, ctx->stream));
+        A.diag = ctx->hero ? nullptr : ctx->diag.p;
+#endif
         if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
         else {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
@@ -950,6 +982,14 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     return VMK_OK;
 }
 
+#ifdef VMK_DIAG
+int vmk_diag_download(vmk_ctx *ctx, float *out, uint64_t n_floats) {
+    if (!ctx || !out || n_floats > ctx->diag.n) return VMK_ERR_ARG;
+    HIP_TRY(hipMemcpyAsync(out, ctx->diag.p, n_floats * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VMK_OK;
+}
+#endif
 int vmk_synchronize(vmk_ctx *ctx) {
     if (!ctx) return VMK_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1107,6 +1147,10 @@ int vmk_precompute_albedo(vmk_ctx *ctx, uint32_t which, uint32_t res, uint32_t s
 
 int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
     if (!ctx) return VMK_ERR_ARG;
+#ifdef VMK_DIAG
+    const uint32_t kind_arg = kind;
+    if (kind == 8) kind = 6;
+#endif
     if (!n || !in || !out || !in_stride || !out_stride || kind > 7) { ctx->error = "vmk_test_eval: bad argument"; return VMK_ERR_ARG; }
     static const uint32_t min_in[8] = {4, 2, 2, 8, 12, 3, 3, 3}, min_out[8] = {8, 6, 8, 8, 13, 6, 67, 1 + 16 * 24};
     if (in_stride < min_in[kind] || out_stride < min_out[kind]) { ctx->error = "vmk_test_eval: stride too small for this kind"; return VMK_ERR_ARG; }
@@ -1126,6 +1170,9 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     if (e == hipSuccess) e = dout.alloc((size_t) n * out_stride);
     if (e == hipSuccess) e = hipMemsetAsync(dout.p, 0, (size_t) n * out_stride * 4, ctx->stream);
     if (e == hipSuccess) {
+#ifdef VMK_DIAG
+        kind = kind_arg;
+#endif
         hipLaunchKernelGGL(k_test, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_scene.p, ctx->d_params.p, kind, n, di.p, in_stride, dout.p, out_stride);
         e = hipGetLastError();
     }
