@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s of the path-tracing hot path on classroom 1920x1080 (BASELINE.json config 3).
+"""Headline benchmark: Mrays/s of the path-tracing hot path (BASELINE.json: classroom 1920x1080 @ 1024 spp).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -7,11 +7,17 @@
 
 A "step" is one megakernel batch: `--spp-per-step` consecutive 1-spp frames of the whole image (K steps accumulate
 K*spp samples per pixel; the default 4 x 256 is the metric's 1024 spp — the largest batch whose staging planes fit one
-launch at 1080p; the drain of the persistent kernel at the end of a launch costs ~2.5 ms whatever the batch, so larger
-batches lose less to it, most of all when 8 GPUs share the image).  Scene tables and BVH are resident in HBM before
-the timed region.  With N ranks the image tiles are sharded (weak per-pixel cost, strong over the image: the total
-work is fixed, so "scaling" is "strong") and every step ends with ONE all-reduce of the float4 framebuffer (RCCL).
+launch at 1080p).  Scene tables and BVH are resident in HBM before the timed region.  With N ranks the image tiles are
+sharded (include/vmk.h vmk_tiles; total work fixed -> "scaling": "strong") and every step ends with the path's one
+exchange, behind the C-ABI: vmk_allreduce_framebuffer (RCCL, on the ctx's exchange stream; the next step's megakernel
+starts at once and only its film resolve waits for it).  torch.distributed is used to start the ranks, to hand rank 0's
+RCCL id to the others and for the barrier / max-over-ranks bookkeeping.
 value = closest + shadow rays traced by all ranks in the timed steps / max-over-ranks wall time.
+
+The timed steps run the megakernel instance WITHOUT the node / triangle tallies (two adds in the innermost traversal
+loops); the tallies behind `roofline.achieved` come from a sibling pass over the same frames afterwards — rays are a pure
+function of (pixel, frame), and the sibling's ray counts are asserted equal to the timed steps'.
+`--config c4 | c5` benches the other single-/multi-GPU BASELINE configurations (glass-of-water hero depth 64; bathroom2 4K).
 Rank 0 prints one JSON line.  cpu_baseline (rank 0, N=1 only) times the CPU oracle (oracle/, test infrastructure) on
 a bounded sample of the same workload.
 """
@@ -40,19 +46,32 @@ def algorithmic_bytes(c, pixels, launches, env_lit, texel_bytes):
     return trav + hit + tex + nee + film, trav
 
 
+CONFIGS = {  # BASELINE.json configs -> (scene, width, height, host options, description)
+    "c3": ("scenes/classroom/vision_scene.json", 1920, 1080, {}, "classroom 1920x1080, env-lit, box filter"),
+    "c2": ("scenes/cbox/cbox_matte.json", 1024, 1024, {}, "cbox 1024x1024, matte-only BSDFs"),
+    "c4": ("scenes/glass-of-water/vision_scene.json", 1024, 1024, {"spectrum": "hero", "max_depth": 64, "min_depth": 3},
+           "glass-of-water 1024x1024, spectrum hero (spectral glass), max_depth 64, min_depth 3"),
+    "c5": ("scenes/bathroom2/vision_scene.json", 3840, 2160, {"max_depth": 64, "missing_assets": "standin"},
+           "bathroom2 3840x2160, max_depth 64, stand-ins for the assets stripped from the reference checkout"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=256)
-    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "classroom", "vision_scene.json"))
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=0, help="default: 256 (64 at 4K, where 256 planes do not fit one launch)")
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json configuration (default c3 = the headline)")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather"], help="form of the per-step exchange (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replay", action="store_true", help="skip the traversal-only replay of the megakernel's own rays")
     ap.add_argument("--no-self-check", action="store_true", help="skip vmk_self_check (profiling runs: keeps every k_render dispatch a timed step)")
+    ap.add_argument("--no-sibling", action="store_true", help="skip the counting sibling pass (roofline.achieved is then null)")
     ap.add_argument("--save", default=None, help="write the final tone-mapped picture (rank 0)")
     a = ap.parse_args()
 
@@ -69,7 +88,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group("nccl")  # RCCL on ROCm: rendezvous, barrier and bookkeeping only — the data path's collective is vmk_allreduce_framebuffer
 
     import __graft_entry__ as g
     if rank == 0:
@@ -77,12 +96,18 @@ def main():
     if dist:
         dist.barrier()
     from vision_amd.pipeline import Pipeline
+    from vision_amd.backend import Backend
     from vision_amd import _abi
 
-    pipe = Pipeline(a.scene, device=local_rank, width=a.width, height=a.height)
+    scene_rel, cw, ch, host_kw, workload = CONFIGS[a.config]
+    scene_path = a.scene or os.path.join(ROOT, scene_rel)
+    width, height = a.width or cw, a.height or ch
+    spp = a.spp_per_step or (64 if width * height > 4000000 else 256)
+    pipe = Pipeline(scene_path, device=local_rank, width=width, height=height, **host_kw)
     pipe.prepare()
+    be = pipe.backend
     # the megakernel variant about to be timed agrees bit for bit with the unit kernel (raises otherwise)
-    checked = 0 if a.no_self_check else pipe.backend.self_check()
+    checked = 0 if a.no_self_check else be.self_check()
     params = pipe.params
     pixels = params.width * params.height
     dev = torch.device("cuda", local_rank)
@@ -90,37 +115,64 @@ def main():
     pipe.use_torch_framebuffer(fb)
     full = torch.zeros_like(fb) if world > 1 else fb
     pipe.set_tiles(a.tile, rank, world)
-    spp = a.spp_per_step
+    if dist:  # RCCL communicator behind the C-ABI: rank 0's id travels over the rendezvous backend
+        idt = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(Backend.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        be.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
     def sync_all():
-        pipe.backend.synchronize()
+        be.synchronize()
+        be.comm_synchronize()
         torch.cuda.synchronize(dev)
         if dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    kernel_ms = []
-
     def step():
-        ms = pipe.render(frames=spp, timed=True)  # HIP events on the ctx stream around the megakernel launch
-        kernel_ms.append(ms)
-        if dist:  # the path's one exchange step: framebuffer all-reduce (disjoint tiles, x + 0 is exact)
-            full.copy_(fb)
-            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        pipe.render(frames=spp, timed=False)  # asynchronous; HIP events on the ctx stream bracket the launch (collect_kernel_ms)
+        if dist:  # the path's one exchange step (disjoint tiles, x + 0 is exact), overlapped with the next step's megakernel
+            if a.exchange == "allreduce":
+                be.allreduce_framebuffer(full.data_ptr())
+            else:
+                be.allgather_framebuffer(pipe.tiles, full.data_ptr())
 
+    be.enable_kernel_timing(True)
+    be.set_traversal_counters(False)  # timed instance: no tallies in the traversal loops (sibling pass below supplies them)
     pipe.invalidate()
     for _ in range(a.warmup):
         step()
     sync_all()
-    pipe.backend.reset_counters()
-    kernel_ms.clear()
+    be.reset_counters()
+    be.collect_kernel_ms()
+    first_frame = pipe.frame_index()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    kernel_ms = be.collect_kernel_ms()
     c = pipe.counters()
+    if a.save and rank == 0:
+        if world > 1:
+            be.set_framebuffer(full.data_ptr())
+        pipe.save_result(a.save)
+        if world > 1:
+            be.set_framebuffer(fb.data_ptr())
+    # ---- sibling pass: the same frames through the tallying instance (film contents are not used afterwards) ----
+    sib = None
+    if not a.no_sibling:
+        be.set_traversal_counters(True)
+        be.reset_counters()
+        for k in range(a.steps):
+            be.render_batch(first_frame + k * spp, spp, tiles=pipe.tiles)
+        be.synchronize()
+        sib = pipe.counters()
+        for k in ("closest_rays", "shadow_rays", "paths", "surface_hits", "tex_fetches"):
+            assert sib[k] == c[k], f"sibling pass traced different work ({k}: {sib[k]} vs {c[k]})"
+        c = dict(c, nodes_visited=sib["nodes_visited"], tris_tested=sib["tris_tested"])
     keys = ["closest_rays", "shadow_rays", "nodes_visited", "tris_tested", "paths", "surface_hits", "tex_fetches"]
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -136,25 +188,32 @@ def main():
     if rank == 0:
         sc = pipe.host_scene.scene
         env_lit = sc.env_light != _abi.INVALID
-        # rank-0 launch: its own counters, its own kernel times
-        b_all, b_trav = algorithmic_bytes(c, pixels // world, a.steps, env_lit, 4)
+        # rank-0 launches: their own tallies (sibling pass), their own kernel times (HIP events on the ctx stream)
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        achieved = b_all / a.steps / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        b_all = b_trav = achieved = None
+        if sib is not None:
+            b_all, b_trav = algorithmic_bytes(c, pixels // world, a.steps, env_lit, 4)
+            achieved = b_all / a.steps / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s on classroom@1024spp, 1/2/4/8 GPUs; HBM GB/s vs roofline",
             "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "classroom scene assets (CC-BY, shipped by the reference) + procedural stand-in for the stripped HDRI",
-            "config": {"workload": f"classroom {params.width}x{params.height}, max_depth {params.max_depth}, min_depth {params.min_depth}, "
-                                   f"{spp} spp per step x {a.steps} steps = {spp * a.steps} spp, env-lit, box filter",
-                       "triangles": int(sc.n_tris), "spp_per_step": spp, "tile": a.tile, "parallelism": f"tiles/{world}"},
+            "dtype": "f32", "data": "scene assets shipped by the reference (CC-BY / CC0) + declared stand-ins for the stripped ones: " + "; ".join(
+                l.split(" ", 1)[1] for l in pipe.host_scene.description.split("\n") if "stand-in" in l)[:400],
+            "config": {"workload": f"{workload}: {params.width}x{params.height}, max_depth {params.max_depth}, min_depth {params.min_depth}, "
+                                   f"{spp} spp per step x {a.steps} steps = {spp * a.steps} spp",
+                       "baseline_config": a.config, "triangles": int(sc.n_tris), "spp_per_step": spp, "tile": a.tile, "parallelism": f"tiles/{world}",
+                       "exchange": (a.exchange + " behind the C-ABI (RCCL), overlapped with the next step") if world > 1 else "none"},
             "self_check": f"megakernel == unit kernel on {checked} pixels of frame 0 (bit-exact)" if checked else "skipped",
             "rays_per_path": rays / max(c_all["paths"], 1),
             "nodes_per_ray": c_all["nodes_visited"] / max(rays, 1), "tris_per_ray": c_all["tris_tested"] / max(rays, 1),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved is not None else None,
                          "traffic": None, "kernel": "k_render", "avg_kernel_ms": avg_ms,
-                         "traversal_GBs": b_trav / a.steps / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0},
+                         "traversal_GBs": b_trav / a.steps / (avg_ms * 1e-3) / 1e9 if (b_trav is not None and avg_ms > 0) else None,
+                         "achieved_is": "ALGORITHMIC (touched) bytes of SURVEY 8(d) per second — a cache-served rate, see hbm_counter_frac and limiter",
+                         "tallies_from": "sibling pass over the same frames with the tallying kernel instance (ray counts asserted equal)" if sib is not None else None},
         }
+        rl = out["roofline"]
         # measured device-to-device copy bandwidth of this GPU in the same run (quote the fraction against both)
         src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)  # 1 GiB each
         dst.copy_(src); torch.cuda.synchronize(dev)
@@ -165,26 +224,46 @@ def main():
         e1.record(); torch.cuda.synchronize(dev)
         copy_gbs = 8 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # read + write
         del src, dst
-        out["roofline"]["measured_copy_GBs"] = copy_gbs
-        out["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+        rl["measured_copy_GBs"] = copy_gbs
+        rl["frac_of_measured_copy"] = achieved / copy_gbs if achieved is not None else None
         # traversal-only replay: the rays the megakernel traces (captured by k_test kind 7, bit-identical to the
         # oracle's) replayed through k_trace; algorithmic bytes = 128 B per node visit + 48 B per triangle test + 44 B per ray
-        if world == 1 and not a.no_replay:
+        if world == 1 and not a.no_replay and not pipe.backend.is_hero:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from gpu_replay import replay
             rp = replay(pipe)
-            out["roofline"]["traversal_replay"] = {k: {"mrays_s": rp[k]["mrays_s"], "achieved_GBs": rp[k]["algorithmic_GBs"], "frac": rp[k]["frac_of_8TBs"],
-                                                       "nodes_per_ray": rp[k]["nodes_per_ray"], "tris_per_ray": rp[k]["tris_per_ray"]}
-                                                   for k in ("closest", "shadow") if k in rp}
-        # HBM traffic of k_render from separate rocprofv3 --pmc passes of this same command (tools/summarize_profiles.py);
-        # only attached when the profiled workload matches this run, otherwise null.
+            rl["traversal_replay"] = {k: {"mrays_s": rp[k]["mrays_s"], "achieved_GBs": rp[k]["algorithmic_GBs"], "frac": rp[k]["frac_of_8TBs"],
+                                          "nodes_per_ray": rp[k]["nodes_per_ray"], "tris_per_ray": rp[k]["tris_per_ray"]}
+                                      for k in ("closest", "shadow") if k in rp}
+        # Counter-derived figures of k_render from separate rocprofv3 --pmc passes of this same command (tools/gpu_profile.sh ->
+        # tools/summarize_profiles.py -> profiles/latest_pmc.json).  Attached only when that profile was taken from THIS build
+        # (device_build_id) on THIS workload; a stale file is refused, not quoted.
         pmc_path = os.path.join(ROOT, "profiles", "latest_pmc.json")
+        rl["limiter"] = "unprofiled build: run tools/gpu_profile.sh"
         if world == 1 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if pmc.get("spp_per_step") == spp and (a.width, a.height) == (1920, 1080):
-                out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = f"profiles/{pmc['tag']}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, (2*FETCH+WRITE)*1024 per launch)"
-                out["roofline"]["algorithmic_bytes_per_launch"] = b_all / a.steps
+            if pmc.get("head") != g.device_build_id():
+                rl["pmc_refused"] = f"profiles/latest_pmc.json was taken from build {pmc.get('head')}, this is {g.device_build_id()}"
+            elif pmc.get("spp_per_step") != spp or pmc.get("config") != a.config:
+                rl["pmc_refused"] = "profiles/latest_pmc.json is for another workload"
+            else:
+                t_s = avg_ms * 1e-3
+                rl["traffic"] = pmc["traffic_bytes_per_launch"]
+                rl["traffic_source"] = f"profiles/{pmc['tag']}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, (2*FETCH+WRITE)*1024 per launch)"
+                rl["algorithmic_bytes_per_launch"] = b_all / a.steps if b_all is not None else None
+                rl["hbm_counter_frac"] = pmc["traffic_bytes_per_launch"] / t_s / 1e9 / HBM_PEAK_GBS
+                if "SQ_INSTS_VALU" in pmc:
+                    valu = pmc["SQ_INSTS_VALU"]  # wave-instructions per launch
+                    rays_launch = rays / a.steps
+                    per_simd_clk = 256 * 4 * 2.4e9  # CUs x SIMDs x max clock (MI355X_MICROARCH.md)
+                    rl["valu"] = {"wave_instructions_per_launch": valu, "per_ray": valu / rays_launch, "rate_G_per_s": valu / t_s / 1e9,
+                                  "ceiling_4cyc_G_per_s": per_simd_clk / 4 / 1e9, "frac_4cyc": valu / t_s / (per_simd_clk / 4),
+                                  "ceiling_2cyc_G_per_s": per_simd_clk / 2 / 1e9, "frac_2cyc": valu / t_s / (per_simd_clk / 2),
+                                  "valu_busy_pct": pmc.get("VALUBusy"), "lane_utilization_pct": pmc.get("VALUUtilization"),
+                                  "note": "4 cycles = one wave64 instruction issued by one wave alone, 2 = SIMD-32 rate with several waves (guide, constants table); VALUBusy is the hardware's own figure",
+                                  "source": f"profiles/{pmc['tag']}_pmc.json"}
+                    rl["limiter"] = "VALU issue (VALUBusy %.0f %%, %.0f %% of the lanes active): HBM sees %.2f of its peak, the touched-bytes rate is served by L2 / Infinity Cache" % (
+                        pmc.get("VALUBusy", float("nan")), pmc.get("VALUUtilization", float("nan")), rl["hbm_counter_frac"])
         if world == 1 and not a.no_cpu_baseline:
             from oracle import oracle_py
             osc = oracle_py.OracleScene(pipe.host_scene)
@@ -192,19 +271,16 @@ def main():
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:
                 cores = os.cpu_count() or 1
-            cores = max(1, min(cores, int(os.environ.get("VMK_CPU_THREADS", "32"))))  # the GPU box grants a CPU share, not the whole host
-            sub, nf = 4, 8  # every 4th 32x32 tile of the same 1920x1080 image, frames 0..7 (about 10-20 s on 32 threads)
+            if os.environ.get("VMK_CPU_THREADS"):
+                cores = max(1, min(cores, int(os.environ["VMK_CPU_THREADS"])))
+            sub, nf = 4, 8  # every 4th 32x32 tile of the same image, frames 0..7 (about 10-20 s)
             t1 = time.perf_counter()
             _, cc = osc.render(params, 0, nf, tiles=_abi.Tiles(a.tile, 0, sub), threads=cores)
             dt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": (cc["closest_rays"] + cc["shadow_rays"]) / dt / 1e6, "unit": "Mrays/s", "cores": cores,
                                    "kind": "port", "sample": f"same scene/resolution, every {sub}th {a.tile}x{a.tile} tile, frames 0-{nf - 1} "
-                                                             f"({cc['paths']} paths, {dt:.1f} s); build CPU restatement (not Vision/ocarina)"}
+                                                             f"({cc['paths']} paths, {dt:.1f} s) on all {cores} host threads this process may use; build CPU restatement (not Vision/ocarina)"}
         print(json.dumps(out), flush=True)
-        if a.save:
-            if world > 1:
-                pipe.backend.set_framebuffer(full.data_ptr())
-            pipe.save_result(a.save)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -266,12 +266,19 @@ typedef struct vmk_render_params {
     uint32_t light_sampler; /* 0 "uniform" (uniform.cpp), 1 "power" (power.cpp; needs vmk_scene::light_alias_offset) */
 } vmk_render_params;
 
-/* Tile ownership for multi-GPU sharding: image cut into tile_size^2 tiles in row-major order, tile t is
- * rendered by this ctx iff owner(t) == rank, owner(t) = bitrev-permuted t mod world. */
+/* Tile ownership for multi-GPU sharding: the image is cut into tile_size^2 tiles; tile (tx, ty) is rendered by this ctx
+ * iff owner(tx, ty) == rank, with
+ *     owner(tx, ty) = (tx + skew * ty) mod world,   skew = vmk_tile_skew(world)
+ * (the smallest odd number >= 0.38 * world that is coprime to world: 1, 3, 5, 7 for world = 2, 4, 8, 16).  Every
+ * world x world block of tiles is a Latin square: each rank owns exactly one tile per row and per column of the block, so
+ * no rank is pinned to a column stripe (what `t mod world` gives when the tiles per row are a multiple of world, e.g. 120 at
+ * 3840 px) or to a band of rows (what a bit-reversed tile index mod a power-of-two world degenerates to), whatever the
+ * resolution.  DESIGN.md section 6. */
 typedef struct vmk_tiles {
     uint32_t tile_size; /* pixels, power of two; 0 => whole image, single owner */
     uint32_t rank, world;
 } vmk_tiles;
+uint32_t vmk_tile_skew(uint32_t world);
 
 typedef struct vmk_counters { /* cumulative since vmk_reset_counters */
     uint64_t closest_rays;    /* trace_closest calls */
@@ -309,13 +316,38 @@ int vmk_reset_accum(vmk_ctx *ctx);
 int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, const vmk_tiles *tiles,
                      float *kernel_ms);
 int vmk_synchronize(vmk_ctx *ctx);
+/* Launch timing without a host sync per batch: with timing enabled every vmk_render_batch(…, kernel_ms = NULL) brackets its
+ * launches with a HIP-event pair on the ctx stream; vmk_collect_kernel_ms waits for the stream and returns the elapsed times
+ * of the calls since the last collect (how bench.py measures the kernel while batches and exchanges overlap). */
+int vmk_enable_kernel_timing(vmk_ctx *ctx, int enabled);
+int vmk_collect_kernel_ms(vmk_ctx *ctx, float *out_ms, uint32_t max_count, uint32_t *count);
 int vmk_download_accum(vmk_ctx *ctx, float *out_rgba /* width*height*4 */);
 /* exposure -> tone map -> (optional second tone map + sRGB, Pipeline::final_picture) -> host RGBA float */
 int vmk_tonemap(vmk_ctx *ctx, int final_picture, float *out_rgba);
 
 int vmk_get_counters(vmk_ctx *ctx, vmk_counters *out);
 int vmk_reset_counters(vmk_ctx *ctx);
+/* nodes_visited / tris_tested are tallied in the traversal's innermost loops (2 VALU per step).  enabled = 0 selects the
+ * megakernel instance without them for the following vmk_render_batch calls (those two counters then stay put; rays, paths,
+ * hits and texture fetches are always counted).  Rays are a pure function of (pixel, frame), so a sibling launch over the
+ * same frames with enabled = 1 returns the tallies of a timed launch exactly (bench.py does that).  Default: enabled. */
+int vmk_set_traversal_counters(vmk_ctx *ctx, int enabled);
 void *vmk_stream(vmk_ctx *ctx); /* hipStream_t the ctx launches on */
+
+/* ---- multi-GPU: the path's one exchange step (the reference is single-GPU, no precedent) --------
+ * One process (or thread) per GPU, one ctx each; image tiles are sharded (vmk_tiles) and every rank's framebuffer holds
+ * its own tiles and zeros elsewhere, so the sum over ranks IS the image, bit for bit (x + 0 is exact).  RCCL is loaded
+ * with dlopen on first use.  The collective runs on a ctx-owned second stream after everything rendered so far; the
+ * render stream is free to start the next vmk_render_batch at once — only that batch's film resolve, the one writer of
+ * the framebuffer, waits for the exchange — so the collective overlaps the next batch's megakernel. */
+#define VMK_COMM_ID_BYTES 128
+int vmk_comm_unique_id(void *id_out /* VMK_COMM_ID_BYTES; ncclGetUniqueId, rank 0 calls it and hands the bytes to the others */);
+int vmk_comm_init(vmk_ctx *ctx, const void *unique_id, int rank, int world); /* ncclCommInitRank: the ctx owns the communicator */
+int vmk_comm_adopt(vmk_ctx *ctx, void *nccl_comm); /* use the host application's own ncclComm_t (not destroyed by the ctx) */
+/* recv_device: width*height*4 floats on this device, distinct from the framebuffer; receives the full image on every rank */
+int vmk_allreduce_framebuffer(vmk_ctx *ctx, void *recv_device);            /* ncclAllReduce(SUM), 2(G-1)/G * S bytes per link */
+int vmk_allgather_framebuffer(vmk_ctx *ctx, const vmk_tiles *tiles, void *recv_device); /* pack owned tiles -> ncclAllGather -> unpack, (G-1)/G * S */
+int vmk_comm_synchronize(vmk_ctx *ctx); /* wait for the exchange stream */
 
 /* ---- BVH introspection + traversal replay (SURVEY §8d traversal-only roofline) ------------------------ */
 typedef struct vmk_accel_info {

@@ -1665,13 +1665,20 @@ inline Swl *path_wavelengths(const vmk_scene *s, uint32_t x, uint32_t y, uint32_
     return &storage;
 }
 
-inline uint32_t bitrev(uint32_t v, uint32_t bits) { uint32_t r = 0; for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | ((v >> i) & 1u); } return r; }
+// tile ownership: include/vmk.h vmk_tiles — owner(tx, ty) = (tx + skew * ty) mod world, skew = the smallest odd number
+// >= 0.38 * world coprime to world (restated here, not linked from the product)
+inline uint32_t tile_skew(uint32_t world) {
+    if (world <= 2) return 1;
+    uint32_t s = (uint32_t) (0.38 * (double) world + 0.999999);
+    if (!(s & 1u)) ++s;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(s, world) != 1) s += 2;
+    return s;
+}
 inline bool tile_owned(const vmk_tiles *t, uint32_t px, uint32_t py, uint32_t width, uint32_t height) {
     if (!t || t->tile_size == 0 || t->world <= 1) return true;
     uint32_t tx = px / t->tile_size, ty = py / t->tile_size;
-    uint32_t ntx = (width + t->tile_size - 1) / t->tile_size;
-    uint32_t tile = ty * ntx + tx;
-    return (tile % t->world) == t->rank; // see DESIGN.md §e: interleaved ownership
+    return (tx + (uint64_t) tile_skew(t->world) * ty) % t->world == t->rank;
 }
 
 }// namespace orc

@@ -147,3 +147,41 @@ def test_hero_spectrum_converges_to_the_srgb_image(built, scene):
         mean[sp] = img[..., :3].astype(np.float64).reshape(-1, 3).mean(0)
     ratio = mean["hero"] / mean["srgb"]
     assert abs(ratio[0] - 1) < 0.015 and abs(ratio[1] - 1) < 0.015 and abs(ratio[2] - 1) < 0.05, ratio
+
+
+def test_tile_ownership_is_a_latin_square_of_tiles(built):
+    """include/vmk.h vmk_tiles: owner(tx, ty) = (tx + skew * ty) mod world.  At 3840 px (120 tiles per row, a multiple of 8)
+    `t mod world` would pin every rank to fixed 32-px column stripes; with the skewed lattice every rank owns exactly one tile
+    in each row and each column of any world x world block, for every world size the bench uses.  The product's skew
+    (vmk_tile_skew, callable without a GPU) and the oracle's restatement agree pixel for pixel."""
+    import ctypes as C
+    from vision_amd.backend import lib_path
+    L = C.CDLL(lib_path())
+    L.vmk_tile_skew.argtypes = [C.c_uint32]; L.vmk_tile_skew.restype = C.c_uint32
+    tiles_x, tiles_y = 3840 // 32, (2160 + 31) // 32
+    for world in (2, 3, 4, 6, 8, 16):
+        skew = L.vmk_tile_skew(world)
+        assert np.gcd(skew, world) == 1 and skew % 2 == 1
+        ty, tx = np.mgrid[0:tiles_y, 0:tiles_x]
+        owner = (tx + skew * ty) % world
+        counts = np.bincount(owner.ravel(), minlength=world)
+        assert counts.max() - counts.min() <= tiles_y  # balanced to within one tile per row
+        for r in range(world):
+            cols = [set(np.nonzero(owner[y] == r)[0] % world) for y in range(world)]
+            assert len(set(map(frozenset, cols))) == world, "a rank owns the same columns in consecutive tile rows"
+        blk = owner[:world, :world]
+        for r in range(world):  # Latin square: once per row and once per column of the block
+            assert ((blk == r).sum(0) == 1).all() and ((blk == r).sum(1) == 1).all()
+    # the oracle's ownership (used by every sharding parity test) is the same function
+    hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_matte.json"), width=96, height=64)
+    osc = oracle_py.OracleScene(hs)
+    for world in (2, 3, 8):
+        skew = L.vmk_tile_skew(world)
+        seen = np.zeros((64, 96), np.int32)
+        for rank in range(world):
+            img, _ = osc.render(hs.params_copy(), 0, 1, tiles=_abi.Tiles(8, rank, world))
+            mine = img[..., 3] != 0
+            py, px = np.mgrid[0:64, 0:96]
+            assert np.array_equal(mine, ((px // 8 + skew * (py // 8)) % world) == rank)
+            seen += mine
+        assert (seen == 1).all()

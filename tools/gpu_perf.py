@@ -11,6 +11,8 @@ w, h, spp, reps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.
 spectrum = os.environ.get("VMK_SPECTRUM") or None  # "hero" / "srgb" override of the scene's spectrum block
 pipe = Pipeline(scene, width=w, height=h, spectrum=spectrum)
 t0 = time.time(); pipe.prepare(); print("prepare", time.time() - t0, "s accel", pipe.accel_info)
+if os.environ.get("VMK_NO_TRAV_COUNT"):
+    pipe.backend.set_traversal_counters(False)  # the megakernel instance without node / triangle tallies
 for r in range(reps):
     pipe.invalidate(); pipe.backend.reset_counters()
     ms = pipe.render(frames=spp)

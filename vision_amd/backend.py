@@ -46,6 +46,17 @@ def lib():
         L.vmk_tonemap.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vmk_get_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.vmk_reset_counters.argtypes = [C.c_void_p]
+        L.vmk_set_traversal_counters.argtypes = [C.c_void_p, C.c_int]
+        L.vmk_tile_skew.argtypes = [C.c_uint32]
+        L.vmk_tile_skew.restype = C.c_uint32
+        L.vmk_comm_unique_id.argtypes = [C.c_void_p]
+        L.vmk_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.vmk_comm_adopt.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_allreduce_framebuffer.argtypes = [C.c_void_p, C.c_void_p]
+        L.vmk_allgather_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vmk_comm_synchronize.argtypes = [C.c_void_p]
+        L.vmk_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        L.vmk_collect_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.vmk_stream.restype = C.c_void_p
         L.vmk_stream.argtypes = [C.c_void_p]
         L.vmk_accel_info_get.argtypes = [C.c_void_p, C.c_void_p]
@@ -83,6 +94,7 @@ class Backend:
 
     def upload_scene(self, host_scene):
         self._check(self._L.vmk_upload_scene(self._h, C.cast(host_scene.tables, C.c_void_p)))
+        self._hero = host_scene.scene.spectrum == _abi.SPECTRUM_HERO
 
     def build_accel(self):
         self._check(self._L.vmk_build_accel(self._h))
@@ -109,6 +121,16 @@ class Backend:
     def synchronize(self):
         self._check(self._L.vmk_synchronize(self._h))
 
+    def enable_kernel_timing(self, enabled=True):
+        self._check(self._L.vmk_enable_kernel_timing(self._h, int(bool(enabled))))
+
+    def collect_kernel_ms(self, max_count=4096):
+        """HIP-event times (ms) of the asynchronous vmk_render_batch calls since the last collect; waits for the ctx stream."""
+        out = np.zeros(max_count, np.float32)
+        n = C.c_uint32(0)
+        self._check(self._L.vmk_collect_kernel_ms(self._h, _ptr(out), max_count, C.byref(n)))
+        return out[:n.value].tolist()
+
     def download_accum(self):
         out = np.zeros((self.params.height, self.params.width, 4), np.float32)
         self._check(self._L.vmk_download_accum(self._h, _ptr(out)))
@@ -124,8 +146,39 @@ class Backend:
         self._check(self._L.vmk_get_counters(self._h, C.byref(c)))
         return c.as_dict()
 
+    @property
+    def is_hero(self):
+        """True when the uploaded scene uses the hero-wavelength spectrum (the vmk_hero.hip megakernel instance)."""
+        return bool(getattr(self, "_hero", False))
+
     def reset_counters(self):
         self._check(self._L.vmk_reset_counters(self._h))
+
+    def set_traversal_counters(self, enabled):
+        """Select the megakernel instance with (default) or without the node / triangle tallies in its traversal loops."""
+        self._check(self._L.vmk_set_traversal_counters(self._h, int(bool(enabled))))
+
+    # ---- multi-GPU exchange (include/vmk.h: vmk_comm_*) ----
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId through the C-ABI: 128 bytes rank 0 hands to the other ranks (any transport)."""
+        buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        rc = lib().vmk_comm_unique_id(buf)
+        if rc != 0:
+            raise BackendError(f"{lib().vmk_last_error(None).decode()} (status {rc})")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self._L.vmk_comm_init(self._h, C.c_char_p(unique_id), rank, world))
+
+    def allreduce_framebuffer(self, recv_device_ptr):
+        self._check(self._L.vmk_allreduce_framebuffer(self._h, C.c_void_p(recv_device_ptr)))
+
+    def allgather_framebuffer(self, tiles, recv_device_ptr):
+        self._check(self._L.vmk_allgather_framebuffer(self._h, C.byref(tiles), C.c_void_p(recv_device_ptr)))
+
+    def comm_synchronize(self):
+        self._check(self._L.vmk_comm_synchronize(self._h))
 
     @property
     def stream(self):

@@ -151,7 +151,10 @@ struct GlobalRayIO {
 // the price is that the parked leaf cannot tighten best_t for the nodes visited meanwhile.  Hits are handed back and new
 // rays taken in batches (VMK_REFILL_QUADS_MIN) because that block costs as much as a node step for the whole wave.
 // Returns the number of rays this quad-lane started (lane q == 0 only) in *n_rays for the callers' counters.
-template<class IO>
+// COUNT: tally node fetches and triangle tests (cnt.nodes / cnt.tris, the algorithmic-bytes side of the roofline); the two adds sit
+// in the innermost loops, so timed launches can run the COUNT = false instance and take the tallies from a sibling launch over
+// the same (deterministic) rays.
+template<class IO, bool COUNT = true>
 VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, uint32_t *n_rays) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
     // ---- per-quad traversal state, replicated in the quad's 4 lanes ----
@@ -187,7 +190,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 // (unused slots hold a far-away point box; the explicit ref test keeps NaN rays, whose slab test passes
                 // everywhere, from walking into them)
                 bool h = hit_box(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, o, inv, best_t, &tn) && ref != kEmptyRef;
-                nn += q == 0 ? 1u : 0u;
+                if constexpr (COUNT) nn += q == 0 ? 1u : 0u;
                 // order key: entry distance (non-negative float bits order like integers) with the lane id in the two low
                 // mantissa bits, so keys are distinct and three unsigned compares rank the children; misses sort last.  The
                 // visiting order only steers culling, it never changes which hit is returned.
@@ -222,7 +225,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
             if (q < count) {
                 float t, u, w;
                 uint32_t inst, prim;
-                ++nt;
+                if constexpr (COUNT) ++nt;
                 if (intersect_tri(S.tri_pos + first + q, o, d, &t, &u, &w, &inst, &prim) && t > 0.f && t < t_max) {
                     bool better = !found || t < bt || (t == bt && (inst < binst || (inst == binst && prim < bprim)));
                     if (better) { found = true; bt = t; binst = inst; bprim = prim; btri = first + q; bu = u; bv = w; }
@@ -283,6 +286,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
 // Trace the rays of all lanes of the wave.  EVERY lane of the wave must call this (convergently); `active` says whether
 // the lane has a ray.  any_hit rays stop at the first valid hit (occlusion query), the others return the closest hit.
 // Returns found; `hit` is filled for closest-hit rays.
+template<bool COUNT = true>
 VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, WaveScratch *ws, Hit &hit, DCounters &cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
@@ -298,7 +302,7 @@ VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, 
     }
     wave_lds_fence();
     LdsRayIO io = {ws, n_act, 0};
-    traverse_core(S, io, ws, cnt, nullptr);
+    traverse_core<LdsRayIO, COUNT>(S, io, ws, cnt, nullptr);
     wave_lds_fence();
     bool res = false;
     if (active) {

@@ -8,8 +8,10 @@ namespace vmkd {
 
 constexpr int kBlock = 256;
 #ifndef VMK_WAVES_PER_SIMD
-#define VMK_WAVES_PER_SIMD 5 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane); measured on classroom with the
-                             // quad traversal: 3: 2015, 4: 2206, 5: 2297, 6: 1825, 8: 1487 Mrays/s
+#define VMK_WAVES_PER_SIMD 6 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane).  Measured on classroom
+                             // (Mrays/s, 32-spp probe, round 2: by-value lobe routines, no SLP, no traversal tallies): 4: 2710, 5: 2990,
+                             // 6: 3230, 7 / 8: 2390 (6.25 KB of LDS per wave caps a CU at 24 waves = 6 per SIMD, so 7 and 8 only lose registers).
+                             // Round 1 (out-pointer lobe routines): 3: 2015, 4: 2206, 5: 2297, 6: 1825, 8: 1487.
 #endif
 #ifndef VMK_MEDIA_WAVES_PER_SIMD
 #define VMK_MEDIA_WAVES_PER_SIMD VMK_WAVES_PER_SIMD
@@ -72,7 +74,7 @@ VD V3 hg_sample(V3 wo, float g, Sampler &sampler, float *f_out) { // 2 draws
 // `dbg` (tests / ray capture only): 16 floats per vertex —
 // [hit inst, prim, bary.xy | light pdf, bsdf pdf towards the light, sampled pdf, occluded | shadow ray o.xyz d.xyz t_max, traced].
 enum : int { kPathGoOn = 0, kPathEnd = 1, kPathTail = 2 };
-template<bool FULL, bool MEDIA>
+template<bool FULL, bool MEDIA, bool COUNT = true>
 __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_params *P, WaveScratch *ws, PathState &ps, Sampler &sampler,
                                            DCounters &cnt, float *dbg, bool active) {
     const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
@@ -83,7 +85,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
     const bool tail = ps.bounces >= max_depth; // the supplement pass (see above)
     Hit hit;
     if (active) cnt.closest++;
-    bool found = traverse_wave(S, ps.ray, active, false, ws, hit, cnt);
+    bool found = traverse_wave<COUNT>(S, ps.ray, active, false, ws, hit, cnt);
     if (dbg && active) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
     bool shade = false; // the lane reached a surface with a material: NEE + scattering follow
     Interaction it;
@@ -158,7 +160,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
         }
     }
     Hit sh;
-    bool occluded = traverse_wave(S, shadow_ray, shade, true, ws, sh, cnt);
+    bool occluded = traverse_wave<COUNT>(S, shadow_ray, shade, true, ws, sh, cnt);
     if (!shade) return pass_through ? kPathGoOn : kPathEnd;
     V3 tr_shadow = mk3(1.f);
     if constexpr (MEDIA) tr_shadow = geometry_Tr(S, P, shadow_ray, P->process_mediums ? (dot(it.ng, shadow_ray.d) > 0.f ? med_out : med_in) : VMK_INVALID SWL_A);
@@ -242,6 +244,7 @@ struct RenderRest {
     uint32_t frame_begin, frame_count;
     uint32_t tile_size, tile_shift, tiles_x, tiles_y, rank, world;
     uint32_t n_slots, n_items, chunk; // chunk: items a wave claims with one atomic
+    const uint32_t *tile_table;       // the owned tiles (row-major tile indices, ascending) or null: every tile (world == 1)
 #ifdef VMK_DIAG
     float *diag; // [n_items][8 vertices][16 floats]: the dbg record of path_bounce (diagnostic builds only)
 #endif
@@ -260,7 +263,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 __device__ __forceinline__ bool slot_to_pixel(const RenderRest &A, uint32_t slot, uint32_t width, uint32_t height, uint32_t *px, uint32_t *py) {
     uint32_t k = slot >> (2u * A.tile_shift), r = slot & (A.tile_size * A.tile_size - 1u);
-    uint32_t tile = A.rank + k * A.world;
+    uint32_t tile = A.tile_table ? A.tile_table[k] : k;
     uint32_t tx = tile % A.tiles_x, ty = tile / A.tiles_x;
     *px = tx * A.tile_size + compact_bits(r); *py = ty * A.tile_size + compact_bits(r >> 1);
     return *px < width && *py < height;
@@ -269,7 +272,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderRest &A, uint32_t slot
 // All four <FULL, MEDIA> variants run at the same waves/SIMD.  (Round 1 pinned the MEDIA variants to 4 after a
 // k_render<true, true> at 96 registers disagreed with the unit kernel; the cause turned out to be the SLP-vectoriser
 // miscompile described in DESIGN.md section 8, which the build now avoids with -fno-slp-vectorize.)
-template<bool FULL, bool MEDIA>
+template<bool FULL, bool MEDIA, bool COUNT>
 __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = A.scene;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
         // (all lanes take part: the traversals inside are wave-cooperative; lanes without a path contribute no ray)
 #ifdef VMK_DIAG
         float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int state = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, dbg, has_path);
+        int state = path_bounce<FULL, MEDIA, COUNT>(S, P, ws, ps, sampler, cnt, dbg, has_path);
         if (has_path && diag_verts < 8u && A.diag) {
             float *q = A.diag + ((size_t) item * 8u + diag_verts) * 16u;
             for (int k = 0; k < 16; ++k) q[k] = dbg[k];
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
             q[15] = u2f(sampler.state);
         }
 #else
-        int state = path_bounce<FULL, MEDIA>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
+        int state = path_bounce<FULL, MEDIA, COUNT>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
 #endif
         if (state == kPathTail && has_path) { // max_depth < 2 only (uniform per launch)
             uint32_t f = item / A.n_slots, px, py;
@@ -370,6 +373,13 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
         uint32_t s = wave_sum(c[i]);
         if (lane == 0 && s) atomicAdd(A.counters + i, (unsigned long long) s);
     }
+}
+
+// the eight ahead-of-time variants
+typedef void (*RenderKernel)(RenderArgs);
+inline RenderKernel select_render_kernel(bool full, bool media, bool count) {
+    if (count) return full ? (media ? k_render<true, true, true> : k_render<true, false, true>) : (media ? k_render<false, true, true> : k_render<false, false, true>);
+    return full ? (media ? k_render<true, true, false> : k_render<true, false, false>) : (media ? k_render<false, true, false> : k_render<false, false, false>);
 }
 
 }// namespace vmkd

@@ -11,6 +11,8 @@
 //   k_test           per-function device unit entry points for the parity tests
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h> // types only: the library is loaded with dlopen on first use (vmk_comm_*)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -24,8 +26,8 @@
 using namespace vmkd;
 
 // the hero-spectrum instance of the megakernel lives in vmk_hero.hip
-hipError_t vmk_hero_occupancy(bool full, bool media, int *blocks_per_cu);
-hipError_t vmk_hero_launch_render(bool full, bool media, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
+hipError_t vmk_hero_occupancy(bool full, bool media, bool count, int *blocks_per_cu);
+hipError_t vmk_hero_launch_render(bool full, bool media, bool count, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -34,6 +36,24 @@ hipError_t vmk_hero_launch_render(bool full, bool media, unsigned blocks, hipStr
     } while (0)
 
 constexpr int kDefaultTile = 32;
+
+// ---- tile ownership (include/vmk.h vmk_tiles) ----
+static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; }
+extern "C" uint32_t vmk_tile_skew(uint32_t world) {
+    if (world <= 2) return 1;
+    uint32_t s = (uint32_t) (0.38 * (double) world + 0.999999);
+    if (!(s & 1u)) ++s;
+    while (gcd_u32(s, world) != 1) s += 2;
+    return s;
+}
+static std::vector<uint32_t> owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t rank, uint32_t world) {
+    std::vector<uint32_t> t;
+    const uint32_t skew = vmk_tile_skew(world);
+    for (uint32_t ty = 0; ty < tiles_y; ++ty)
+        for (uint32_t tx = 0; tx < tiles_x; ++tx)
+            if ((tx + (uint64_t) skew * ty) % world == rank) t.push_back(ty * tiles_x + tx);
+    return t;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // LBVH build
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const DScene S, uint32_t n, co
     uint32_t n_rays = 0;
     if (S.n_tris == 0) { // nothing to hit
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { io.store((int) i, false, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); ++n_rays; }
-    } else traverse_core(S, io, ws, cnt, &n_rays);
+    } else traverse_core<GlobalRayIO, true>(S, io, ws, cnt, &n_rays);
     if (any_hit) cnt.shadow += n_rays; else cnt.closest += n_rays;
     uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
     for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
@@ -544,6 +564,7 @@ struct vmk_ctx {
     // scene
     bool scene_ready{false}, accel_ready{false}, params_ready{false};
     bool full_materials{true}; // scene has mix / principled_bsdf -> lobe-set variant of the megakernel
+    bool count_traversal{true}; // vmk_set_traversal_counters: launch the megakernel instance that tallies node fetches / triangle tests
     bool hero{false};          // vmk_scene::spectrum == VMK_SPECTRUM_HERO -> the vmk_hero.hip instance of the megakernel
     DevBuf<float> rgb2spec, spd;
     uint32_t n_tris{0};
@@ -572,12 +593,82 @@ struct vmk_ctx {
     float4 *fb{nullptr};
     DevBuf<uint32_t> queue;
     DevBuf<unsigned long long> counters;
+    // tile ownership table of the last sharded launch (include/vmk.h vmk_tiles)
+    DevBuf<uint32_t> tile_table;
+    uint32_t tt_key[5]{0, 0, 0, 0, 0}; // tiles_x, tiles_y, rank, world, count
+    // multi-GPU (RCCL, loaded on first use)
+    void *comm{nullptr};
+    bool comm_owned{false};
+    hipStream_t comm_stream{nullptr};
+    hipEvent_t render_done{nullptr}, comm_done{nullptr};
+    bool comm_pending{false};
+    DevBuf<float4> gather_send, gather_recv;
+    // asynchronous launch timing (vmk_collect_kernel_ms): one HIP-event pair per vmk_render_batch call since the last collect
+    bool timing{false};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> time_pool;
+    size_t time_used{0};
 #ifdef VMK_DIAG
     DevBuf<float> diag;
 #endif
 };
 
 static thread_local std::string g_null_error;
+
+// ---------------------------------------------------------------------------------------------------------
+// RCCL, loaded on first use: a single-GPU host never needs librccl.so to be present
+// ---------------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib{nullptr};
+    decltype(&ncclGetUniqueId) GetUniqueId{nullptr};
+    decltype(&ncclCommInitRank) CommInitRank{nullptr};
+    decltype(&ncclCommDestroy) CommDestroy{nullptr};
+    decltype(&ncclAllReduce) AllReduce{nullptr};
+    decltype(&ncclAllGather) AllGather{nullptr};
+    decltype(&ncclGetErrorString) GetErrorString{nullptr};
+};
+static RcclApi g_rccl;
+static bool rccl_load(std::string &err) {
+    if (g_rccl.lib) return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { err = std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : "?"); return false; }
+    RcclApi a; a.lib = h;
+#define VMK_SYM(field, name) a.field = (decltype(a.field)) dlsym(h, name); if (!a.field) { err = std::string("RCCL symbol missing: ") + name; dlclose(h); return false; }
+    VMK_SYM(GetUniqueId, "ncclGetUniqueId") VMK_SYM(CommInitRank, "ncclCommInitRank") VMK_SYM(CommDestroy, "ncclCommDestroy")
+    VMK_SYM(AllReduce, "ncclAllReduce") VMK_SYM(AllGather, "ncclAllGather") VMK_SYM(GetErrorString, "ncclGetErrorString")
+#undef VMK_SYM
+    g_rccl = a;
+    return true;
+}
+static void vmk_comm_release(vmk_ctx *ctx) {
+    if (ctx->comm_stream) (void) hipStreamSynchronize(ctx->comm_stream);
+    if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) (void) g_rccl.CommDestroy((ncclComm_t) ctx->comm);
+    ctx->comm = nullptr; ctx->comm_owned = false; ctx->comm_pending = false;
+    if (ctx->render_done) (void) hipEventDestroy(ctx->render_done);
+    if (ctx->comm_done) (void) hipEventDestroy(ctx->comm_done);
+    if (ctx->comm_stream) (void) hipStreamDestroy(ctx->comm_stream);
+    ctx->render_done = ctx->comm_done = nullptr; ctx->comm_stream = nullptr;
+}
+// gather / scatter of owned tiles for the all-gather form of the exchange: `table` lists, rank after rank, the tiles each rank
+// owns (per_rank entries each, padded with VMK_INVALID); a tile is tile_size^2 float4 in row-major pixel order
+__global__ void k_pack_tiles(const float4 *fb, float4 *send, const uint32_t *table, uint32_t n_owned, uint32_t tile_size, uint32_t tiles_x, uint32_t width, uint32_t height) {
+    const uint32_t per_tile = tile_size * tile_size;
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t) n_owned * per_tile) return;
+    uint32_t k = (uint32_t) (i / per_tile), r = (uint32_t) (i % per_tile), tile = table[k];
+    uint32_t px = (tile % tiles_x) * tile_size + r % tile_size, py = (tile / tiles_x) * tile_size + r / tile_size;
+    send[i] = (tile != VMK_INVALID && px < width && py < height) ? fb[(size_t) py * width + px] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void k_unpack_tiles(const float4 *recv, float4 *full, const uint32_t *table_all, uint32_t world, uint32_t per_rank, uint32_t tile_size, uint32_t tiles_x, uint32_t width, uint32_t height) {
+    const uint32_t per_tile = tile_size * tile_size;
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t) world * per_rank * per_tile) return;
+    uint32_t k = (uint32_t) (i / per_tile), r = (uint32_t) (i % per_tile), tile = table_all[k];
+    if (tile == VMK_INVALID) return;
+    uint32_t px = (tile % tiles_x) * tile_size + r % tile_size, py = (tile / tiles_x) * tile_size + r / tile_size;
+    if (px < width && py < height) full[(size_t) py * width + px] = recv[i];
+}
 
 extern "C" {
 
@@ -618,7 +709,9 @@ void vmk_destroy(vmk_ctx *ctx) {
     ctx->instances.release(); ctx->materials.release(); ctx->lights.release(); ctx->mediums.release(); ctx->textures.release(); ctx->tex_data.release();
     ctx->alias_prob.release(); ctx->alias_func.release(); ctx->alias_idx.release(); ctx->srgb_lut.release(); ctx->luts.release(); ctx->rgb2spec.release(); ctx->spd.release();
     ctx->nodes.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release(); ctx->stage.release();
-    ctx->queue.release(); ctx->counters.release();
+    ctx->queue.release(); ctx->counters.release(); ctx->tile_table.release(); ctx->gather_send.release(); ctx->gather_recv.release();
+    vmk_comm_release(ctx);
+    for (auto &pr : ctx->time_pool) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
@@ -910,6 +1003,7 @@ int vmk_reset_accum(vmk_ctx *ctx) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->params_ready || !ctx->fb) { ctx->error = "vmk_reset_accum: no framebuffer"; return VMK_ERR_STATE; }
     HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->comm_pending) { HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->comm_done, 0)); ctx->comm_pending = false; }
     HIP_TRY(hipMemsetAsync(ctx->fb, 0, (size_t) ctx->params.width * ctx->params.height * sizeof(float4), ctx->stream));
     return VMK_OK;
 }
@@ -932,8 +1026,19 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     A.tile_size = ts; A.tile_shift = shift;
     A.tiles_x = (ctx->params.width + ts - 1) / ts; A.tiles_y = (ctx->params.height + ts - 1) / ts;
     uint32_t n_tiles = A.tiles_x * A.tiles_y;
-    uint32_t owned = n_tiles > rank ? (n_tiles - rank + world - 1) / world : 0;
-    A.rank = rank; A.world = world;
+    uint32_t owned = n_tiles;
+    A.rank = rank; A.world = world; A.tile_table = nullptr;
+    if (world > 1) { // owner(tx, ty) = (tx + skew * ty) mod world: the owned tiles, ascending, as a device table
+        if (ctx->tt_key[0] != A.tiles_x || ctx->tt_key[1] != A.tiles_y || ctx->tt_key[2] != rank || ctx->tt_key[3] != world) {
+            std::vector<uint32_t> table = owned_tiles(A.tiles_x, A.tiles_y, rank, world);
+            HIP_TRY(hipStreamSynchronize(ctx->stream)); // a launch in flight may still read the old table
+            HIP_TRY(ctx->tile_table.upload(table.data(), table.size(), ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->tt_key[0] = A.tiles_x; ctx->tt_key[1] = A.tiles_y; ctx->tt_key[2] = rank; ctx->tt_key[3] = world; ctx->tt_key[4] = (uint32_t) table.size();
+        }
+        owned = ctx->tt_key[4];
+        A.tile_table = ctx->tile_table.p;
+    }
     uint64_t n_slots = (uint64_t) owned * ts * ts;
     if (n_slots == 0) return VMK_OK;
     if (n_slots > 0x7fffffffull) { ctx->error = "vmk_render_batch: too many pixels"; return VMK_ERR_ARG; }
@@ -947,10 +1052,21 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     A.stage = ctx->stage.p;
     int per_cu = 0;
     const bool media = ctx->params.process_mediums != 0;
-    auto kernel = ctx->full_materials ? (media ? k_render<true, true> : k_render<true, false>) : (media ? k_render<false, true> : k_render<false, false>);
-    if (ctx->hero) HIP_TRY(vmk_hero_occupancy(ctx->full_materials, media, &per_cu));
+    const bool count = ctx->count_traversal;
+    auto kernel = select_render_kernel(ctx->full_materials, media, count);
+    if (ctx->hero) HIP_TRY(vmk_hero_occupancy(ctx->full_materials, media, count, &per_cu));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (!kernel_ms && ctx->timing) { // asynchronous timing: events only, read back by vmk_collect_kernel_ms
+        if (ctx->time_used == ctx->time_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            ctx->time_pool.emplace_back(a, b);
+        }
+        t0 = ctx->time_pool[ctx->time_used].first; t1 = ctx->time_pool[ctx->time_used].second; ++ctx->time_used;
+        HIP_TRY(hipEventRecord(t0, ctx->stream));
+    }
     if (kernel_ms) HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     for (uint32_t done = 0; done < frame_count; done += per_launch) {
         A.frame_begin = frame_begin + done; A.frame_count = std::min(per_launch, frame_count - done);
@@ -966,19 +1082,38 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         HIP_TRY(hipMemsetAsync(ctx->diag.p, 0, (size_t) n_items * 128 * 4, ctx->stream));
         A.diag = ctx->hero ? nullptr : ctx->diag.p;
 #endif
-        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
+        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, count, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
         else {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
             HIP_TRY(hipGetLastError());
         }
+        if (ctx->comm_pending) { HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->comm_done, 0)); ctx->comm_pending = false; } // the exchange of the previous batch reads fb
         hipLaunchKernelGGL(k_film_resolve, dim3((A.n_slots + 255) / 256), dim3(256), 0, ctx->stream, static_cast<const RenderRest &>(A));
         HIP_TRY(hipGetLastError());
     }
+    if (t1) HIP_TRY(hipEventRecord(t1, ctx->stream));
     if (kernel_ms) {
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(hipEventSynchronize(ctx->ev1));
         HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
     }
+    return VMK_OK;
+}
+
+int vmk_enable_kernel_timing(vmk_ctx *ctx, int enabled) {
+    if (!ctx) return VMK_ERR_ARG;
+    ctx->timing = enabled != 0;
+    if (!ctx->timing) ctx->time_used = 0;
+    return VMK_OK;
+}
+int vmk_collect_kernel_ms(vmk_ctx *ctx, float *out_ms, uint32_t max_count, uint32_t *count) {
+    if (!ctx || !count || (max_count && !out_ms)) return VMK_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    uint32_t n = 0;
+    for (size_t i = 0; i < ctx->time_used && n < max_count; ++i, ++n) HIP_TRY(hipEventElapsedTime(out_ms + n, ctx->time_pool[i].first, ctx->time_pool[i].second));
+    *count = n;
+    ctx->time_used = 0;
     return VMK_OK;
 }
 
@@ -990,6 +1125,108 @@ int vmk_diag_download(vmk_ctx *ctx, float *out, uint64_t n_floats) {
     return VMK_OK;
 }
 #endif
+// ---- multi-GPU exchange (one collective per batch over RCCL / xGMI) ----
+int vmk_comm_unique_id(void *id_out) {
+    if (!id_out) return VMK_ERR_ARG;
+    std::string err;
+    if (!rccl_load(err)) { g_null_error = "vmk_comm_unique_id: " + err; return VMK_ERR_UNSUPPORTED; }
+    static_assert(sizeof(ncclUniqueId) == VMK_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_null_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return VMK_ERR_HIP; }
+    std::memcpy(id_out, &id, sizeof(id));
+    return VMK_OK;
+}
+static int comm_prepare(vmk_ctx *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    if (!ctx->render_done) HIP_TRY(hipEventCreateWithFlags(&ctx->render_done, hipEventDisableTiming));
+    if (!ctx->comm_done) HIP_TRY(hipEventCreateWithFlags(&ctx->comm_done, hipEventDisableTiming));
+    return VMK_OK;
+}
+int vmk_comm_init(vmk_ctx *ctx, const void *unique_id, int rank, int world) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!unique_id || world < 1 || rank < 0 || rank >= world) { ctx->error = "vmk_comm_init: bad argument"; return VMK_ERR_ARG; }
+    if (!rccl_load(ctx->error)) return VMK_ERR_UNSUPPORTED;
+    vmk_comm_release(ctx);
+    int rc = comm_prepare(ctx);
+    if (rc != VMK_OK) return rc;
+    ncclUniqueId id; std::memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) { ctx->error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); return VMK_ERR_HIP; }
+    ctx->comm = comm; ctx->comm_owned = true;
+    return VMK_OK;
+}
+int vmk_comm_adopt(vmk_ctx *ctx, void *nccl_comm) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!nccl_comm) { ctx->error = "vmk_comm_adopt: null communicator"; return VMK_ERR_ARG; }
+    if (!rccl_load(ctx->error)) return VMK_ERR_UNSUPPORTED;
+    vmk_comm_release(ctx);
+    int rc = comm_prepare(ctx);
+    if (rc != VMK_OK) return rc;
+    ctx->comm = nccl_comm; ctx->comm_owned = false;
+    return VMK_OK;
+}
+// enqueue "after everything rendered so far" on the exchange stream; the render stream goes on with the next batch and
+// only its film resolve (the one writer of the framebuffer) waits for the exchange (vmk_render_batch)
+static int comm_begin(vmk_ctx *ctx, const char *who) {
+    if (!ctx->comm) { ctx->error = std::string(who) + ": no communicator (vmk_comm_init / vmk_comm_adopt)"; return VMK_ERR_STATE; }
+    if (!ctx->params_ready || !ctx->fb) { ctx->error = std::string(who) + ": no framebuffer"; return VMK_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->render_done, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->render_done, 0));
+    return VMK_OK;
+}
+int vmk_allreduce_framebuffer(vmk_ctx *ctx, void *recv_device) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!recv_device || recv_device == (void *) ctx->fb) { if (ctx) ctx->error = "vmk_allreduce_framebuffer: recv_device must be a second width*height*4 float buffer (the framebuffer keeps this rank's tiles only)"; return VMK_ERR_ARG; }
+    int rc = comm_begin(ctx, "vmk_allreduce_framebuffer");
+    if (rc != VMK_OK) return rc;
+    const size_t count = (size_t) ctx->params.width * ctx->params.height * 4;
+    ncclResult_t r = g_rccl.AllReduce(ctx->fb, recv_device, count, ncclFloat32, ncclSum, (ncclComm_t) ctx->comm, ctx->comm_stream);
+    if (r != ncclSuccess) { ctx->error = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r); return VMK_ERR_HIP; }
+    HIP_TRY(hipEventRecord(ctx->comm_done, ctx->comm_stream));
+    ctx->comm_pending = true;
+    return VMK_OK;
+}
+int vmk_allgather_framebuffer(vmk_ctx *ctx, const vmk_tiles *tiles, void *recv_device) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!tiles || !tiles->tile_size || (tiles->tile_size & (tiles->tile_size - 1)) || !tiles->world || tiles->rank >= tiles->world || !recv_device || recv_device == (void *) ctx->fb) { ctx->error = "vmk_allgather_framebuffer: bad argument"; return VMK_ERR_ARG; }
+    int rc = comm_begin(ctx, "vmk_allgather_framebuffer");
+    if (rc != VMK_OK) return rc;
+    const uint32_t ts = tiles->tile_size, world = tiles->world, W = ctx->params.width, H = ctx->params.height;
+    const uint32_t tiles_x = (W + ts - 1) / ts, tiles_y = (H + ts - 1) / ts;
+    std::vector<std::vector<uint32_t>> own(world);
+    uint32_t per_rank = 0;
+    for (uint32_t r = 0; r < world; ++r) { own[r] = world > 1 ? owned_tiles(tiles_x, tiles_y, r, world) : std::vector<uint32_t>(); if (world == 1) { own[0].resize((size_t) tiles_x * tiles_y); for (uint32_t t = 0; t < tiles_x * tiles_y; ++t) own[0][t] = t; } per_rank = std::max<uint32_t>(per_rank, (uint32_t) own[r].size()); }
+    std::vector<uint32_t> table_all((size_t) world * per_rank, VMK_INVALID);
+    for (uint32_t r = 0; r < world; ++r) std::copy(own[r].begin(), own[r].end(), table_all.begin() + (size_t) r * per_rank);
+    DevBuf<uint32_t> d_table; // (small: rebuilt per call; the exchange happens once per batch of seconds)
+    const size_t per_rank_px = (size_t) per_rank * ts * ts;
+    hipError_t e = d_table.upload(table_all.data(), table_all.size(), ctx->comm_stream);
+    if (e == hipSuccess && ctx->gather_send.n < per_rank_px) e = ctx->gather_send.alloc(per_rank_px);
+    if (e == hipSuccess && ctx->gather_recv.n < per_rank_px * world) e = ctx->gather_recv.alloc(per_rank_px * world);
+    if (e != hipSuccess) { d_table.release(); ctx->error = std::string("vmk_allgather_framebuffer: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned) ((per_rank_px + 255) / 256)), dim3(256), 0, ctx->comm_stream, ctx->fb, ctx->gather_send.p, d_table.p + (size_t) tiles->rank * per_rank, per_rank, ts, tiles_x, W, H);
+    ncclResult_t r = g_rccl.AllGather(ctx->gather_send.p, ctx->gather_recv.p, per_rank_px * 4, ncclFloat32, (ncclComm_t) ctx->comm, ctx->comm_stream);
+    if (r != ncclSuccess) { (void) hipStreamSynchronize(ctx->comm_stream); d_table.release(); ctx->error = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); return VMK_ERR_HIP; }
+    hipLaunchKernelGGL(k_unpack_tiles, dim3((unsigned) ((per_rank_px * world + 255) / 256)), dim3(256), 0, ctx->comm_stream, ctx->gather_recv.p, (float4 *) recv_device, d_table.p, world, per_rank, ts, tiles_x, W, H);
+    e = hipEventRecord(ctx->comm_done, ctx->comm_stream);
+    ctx->comm_pending = true;
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->comm_stream); // d_table is freed below (the all-reduce form stays asynchronous)
+    d_table.release();
+    if (e != hipSuccess) { ctx->error = std::string("vmk_allgather_framebuffer: ") + hipGetErrorString(e); return VMK_ERR_HIP; }
+    return VMK_OK;
+}
+int vmk_comm_synchronize(vmk_ctx *ctx) {
+    if (!ctx) return VMK_ERR_ARG;
+    if (!ctx->comm_stream) return VMK_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->comm_stream));
+    ctx->comm_pending = false;
+    return VMK_OK;
+}
 int vmk_synchronize(vmk_ctx *ctx) {
     if (!ctx) return VMK_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1025,6 +1262,11 @@ int vmk_get_counters(vmk_ctx *ctx, vmk_counters *out) {
     HIP_TRY(hipMemcpyAsync(h, ctx->counters.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     out->closest_rays = h[0]; out->shadow_rays = h[1]; out->nodes_visited = h[2]; out->tris_tested = h[3]; out->paths = h[4]; out->surface_hits = h[5]; out->tex_fetches = h[6];
+    return VMK_OK;
+}
+int vmk_set_traversal_counters(vmk_ctx *ctx, int enabled) {
+    if (!ctx) return VMK_ERR_ARG;
+    ctx->count_traversal = enabled != 0;
     return VMK_OK;
 }
 int vmk_reset_counters(vmk_ctx *ctx) {

@@ -94,11 +94,10 @@ class Pipeline:
 
     def __init__(self, scene_file, device=0, width=0, height=0, max_depth=-1, min_depth=-1, procedural_env=True,
                  drop_unsupported_lights=False, mediums=False, spectrum=None):
-        self._mediums = mediums
-        self._spectrum = spectrum  # None: the scene's own "spectrum" block; "srgb" / "hero" override it
-        self.host_scene = HostScene(scene_file, width=width, height=height, max_depth=max_depth, min_depth=min_depth,
-                                    procedural_env=procedural_env, drop_unsupported_lights=drop_unsupported_lights,
-                                    mediums=mediums, spectrum=spectrum)
+        # every option of the scene load is kept: change_resolution re-derives the tables with the same ones
+        self._host_options = dict(max_depth=max_depth, min_depth=min_depth, procedural_env=procedural_env,
+                                  drop_unsupported_lights=drop_unsupported_lights, mediums=mediums, spectrum=spectrum)
+        self.host_scene = HostScene(scene_file, width=width, height=height, **self._host_options)
         self.params = self.host_scene.params_copy()
         self.backend = Backend(device)
         self.frame_buffer = FrameBuffer(self)
@@ -131,9 +130,11 @@ class Pipeline:
         """Pipeline::change_resolution: re-derives the camera matrices for the new film size (sensor.cpp:58-71)."""
         path = self.host_scene.json_path
         self.host_scene.close()
-        self.host_scene = HostScene(path, width=width, height=height, max_depth=self.params.max_depth,
-                                    min_depth=self.params.min_depth, mediums=self._mediums, spectrum=self._spectrum)
+        self.host_scene = HostScene(path, width=width, height=height, **self._host_options)
         self.params = self.host_scene.params_copy()
+        # vmk_set_render_params falls back to a ctx-owned film of the new size: a caller-owned tensor of the old size is
+        # no longer bound (use_torch_framebuffer again with a tensor of the new shape)
+        self._torch_fb = None
         self.backend.set_render_params(self.params)
         self.invalidate()
 
