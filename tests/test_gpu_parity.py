@@ -457,37 +457,63 @@ def test_glass_of_water_agrees_with_the_reference_render(backend):
     assert (ratio > 0.85).all() and (ratio < 1.15).all(), ratio
 
 
+class _DevBuf:
+    """float32 device buffer through the HIP runtime libvmk.so already loaded (no torch in this process: a second HIP
+    runtime — torch bundles its own — does not see the GPU once the first one holds it)."""
+
+    def __init__(self, shape, fill=0.0):
+        import ctypes as C
+        self._hip = C.CDLL("libamdhip64.so")
+        self.shape = shape
+        self.nbytes = int(np.prod(shape)) * 4
+        p = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(p), C.c_size_t(self.nbytes)) == 0
+        self.ptr = p.value
+        host = np.full(shape, fill, np.float32)
+        assert self._hip.hipMemcpy(C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(self.nbytes), 1) == 0
+
+    def numpy(self):
+        import ctypes as C
+        out = np.zeros(self.shape, np.float32)
+        assert self._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(self.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        import ctypes as C
+        self._hip.hipFree(C.c_void_p(self.ptr))
+
+
 def test_exchange_behind_the_c_abi_with_a_one_rank_communicator(backend):
     """vmk_comm_init / vmk_allreduce_framebuffer / vmk_allgather_framebuffer (RCCL behind the C-ABI) on a 1-rank
     communicator: both forms of the exchange deliver the framebuffer bit for bit into the receive buffer, the exchange of
     batch k overlaps batch k+1 (whose film resolve waits for it), and the asynchronous launch timing returns one time per batch.
     The N = 2 data path is covered on CPU (gloo) in test_oracle_render.py; the 1 -> 8 curve is the driver's run."""
-    import torch
     from vision_amd import _abi
     from vision_amd.backend import Backend
     hs, p, osc, _ = _load(backend, "scenes/cbox/cbox_materials.json", 70, 40)
-    dev = torch.device("cuda", 0)
-    fb = torch.zeros((40, 70, 4), dtype=torch.float32, device=dev)
-    full_a = torch.full_like(fb, -1.0); full_b = torch.full_like(fb, -1.0); full_g = torch.full_like(fb, -1.0)
-    backend.set_framebuffer(fb.data_ptr())
+    fb = _DevBuf((40, 70, 4), 0.0)
+    full_a, full_b, full_g = _DevBuf((40, 70, 4), -1.0), _DevBuf((40, 70, 4), -1.0), _DevBuf((40, 70, 4), -1.0)
+    backend.set_framebuffer(fb.ptr)
     backend.comm_init(Backend.comm_unique_id(), 0, 1)
     backend.enable_kernel_timing(True)
     backend.reset_accum()
-    backend.render_batch(0, 2)                       # batch 0
-    backend.allreduce_framebuffer(full_a.data_ptr())  # its exchange, on the exchange stream
-    backend.render_batch(2, 2)                       # batch 1 starts at once; its film resolve waits for the exchange
-    backend.allreduce_framebuffer(full_b.data_ptr())
-    backend.allgather_framebuffer(_abi.Tiles(16, 0, 1), full_g.data_ptr())
+    backend.render_batch(0, 2)                 # batch 0
+    backend.allreduce_framebuffer(full_a.ptr)  # its exchange, on the exchange stream
+    backend.render_batch(2, 2)                 # batch 1 starts at once; its film resolve waits for the exchange
+    backend.allreduce_framebuffer(full_b.ptr)
+    backend.allgather_framebuffer(_abi.Tiles(16, 0, 1), full_g.ptr)
     backend.comm_synchronize()
     times = backend.collect_kernel_ms()
     backend.enable_kernel_timing(False)
     assert len(times) == 2 and all(t > 0 for t in times)
     ref2, _ = osc.render(p, 0, 2)
     ref4, _ = osc.render(p, 0, 4)
-    a, b, gth, own = full_a.cpu().numpy(), full_b.cpu().numpy(), full_g.cpu().numpy(), fb.cpu().numpy()
+    a, b, gth, own = full_a.numpy(), full_b.numpy(), full_g.numpy(), fb.numpy()
     assert np.array_equal(a.view(np.uint32), ref2.view(np.uint32))      # the exchange saw batch 0's film, not batch 1's
     assert np.array_equal(b.view(np.uint32), ref4.view(np.uint32))
     assert np.array_equal(gth.view(np.uint32), own.view(np.uint32)) and np.array_equal(own.view(np.uint32), ref4.view(np.uint32))
     with pytest.raises(Exception, match="second"):
-        backend.allreduce_framebuffer(fb.data_ptr())  # in place would double-count on the next batch: refused
+        backend.allreduce_framebuffer(fb.ptr)  # in place would double-count on the next batch: refused
     backend.set_framebuffer(None)
+    for d in (fb, full_a, full_b, full_g):
+        d.free()

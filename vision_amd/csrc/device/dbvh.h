@@ -15,7 +15,10 @@
 
 namespace vmkd {
 
-constexpr int kQuadStack = 64; // stack entries per ray; a build whose worst-case need exceeds it is rejected
+#ifndef VMK_QUAD_STACK
+#define VMK_QUAD_STACK 64
+#endif
+constexpr int kQuadStack = VMK_QUAD_STACK; // stack entries per ray; a build whose worst-case need exceeds it is rejected
 constexpr int32_t kTravDone = 0x7fffffff;
 
 struct Hit { uint32_t inst, prim, tri; V2 bary; };
