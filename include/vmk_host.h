@@ -34,6 +34,10 @@ typedef struct vmk_host_options {
                                  * 1: honour it (mediums.process, global medium, per-shape inside/outside, sensor medium) */
     uint32_t spectrum;          /* 0: keep the scene's "spectrum" block; 1: force spectrum/srgb; 2: force spectrum/hero (the shipped
                                  * scenes carry the hero line commented out — this flips it without editing the file) */
+    uint32_t missing_assets;    /* 0: a mesh / texture file the scene names but the disk lacks is an error; 1 ("standin"): a missing mesh is
+                                 * skipped and a missing texture becomes a 1x1 mid-grey constant, each listed by vmk_host_describe as
+                                 * "... (stand-in: file missing ...)" — for scenes whose large assets are stripped from the reference
+                                 * checkout (bathroom2: 10 meshes, WoodPanel.png, the HDRI) */
 } vmk_host_options;
 
 /* Register decoded pixels for an image file so the loader does not need a decoder for it.  `path` is matched

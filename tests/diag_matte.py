@@ -3,7 +3,7 @@
 prints the mismatch count, the counters of both sides and saves both images (gpurun_out/diag_<tag>.npz)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # (lives under tests/: it uses the CPU oracle as the checker)
 sys.path.insert(0, ROOT)
 from vision_amd.backend import Backend
 from vision_amd.host import HostScene

@@ -218,3 +218,46 @@ def test_hero_uplift_round_trip(built):
     o6 = osc.test_eval(hs.params, 60, np.array([[3.0, 2.0, 0.5, 0.3]], np.float32), 24)[0]
     o1 = osc.test_eval(hs.params, 60, np.array([[0.5, 1 / 3, 1 / 12, 0.3]], np.float32), 24)[0]
     assert np.allclose(o6[9:12], 6 * o1[6:9], rtol=1e-5)
+
+
+def test_bathroom2_loads_with_declared_standins(built):
+    """BASELINE config 5's scene: the reference checkout lacks 10 meshes, WoodPanel.png and the HDRI.  Without the option the
+    loader fails on the first missing asset; with vmk_host_options.missing_assets = standin every substitution is listed."""
+    path = os.path.join(ROOT, "scenes/bathroom2/vision_scene.json")
+    with pytest.raises(HostError, match="file missing"):
+        HostScene(path, width=64, height=36)
+    hs = HostScene(path, width=64, height=36, missing_assets="standin")
+    lines = [l for l in hs.description.split("\n") if "stand-in" in l]
+    assert sum("model_skipped" in l for l in lines) == 10 and any("WoodPanel.png" in l and "constant_grey" in l for l in lines)
+    assert any("spruit_sunrise_2k.hdr" in l and "procedural_sky" in l for l in lines)
+    assert hs.scene.n_tris == 383795 and hs.scene.n_lights == 2 and hs.params.max_depth == 64
+
+
+def test_malformed_assets_fail_instead_of_hanging(built, tmp_path):
+    """A face record strtol cannot advance over, and a truncated / zero-run RLE scanline in a .hdr, used to spin forever."""
+    import json
+    text = open(os.path.join(ROOT, "scenes", "cbox", "cbox_matte.json")).read()
+    sc = json.loads("\n".join(l for l in text.split("\n") if not l.startswith("//")))
+    with open(os.path.join(tmp_path, "bad.obj"), "w") as f:
+        f.write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 x3\n")
+    with open(os.path.join(tmp_path, "ok.obj"), "w") as f:
+        f.write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3 # trailing comment\n")
+    ident = {"type": "matrix4x4", "param": {"matrix4x4": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]}}
+    for fn, ok in (("ok.obj", True), ("bad.obj", False)):
+        sc2 = dict(sc); sc2["shapes"] = list(sc["shapes"]) + [{"type": "model", "name": "m", "param": {"fn": fn, "material": sc["materials"][0]["name"], "transform": ident}}]
+        path = os.path.join(tmp_path, fn + ".json"); json.dump(sc2, open(path, "w"))
+        if ok:
+            assert HostScene(path, width=16, height=16).scene.n_tris == 37
+        else:
+            with pytest.raises(HostError, match="malformed face"):
+                HostScene(path, width=16, height=16)
+    # truncated RLE .hdr as an environment map: refused by the native decoder, then reported as undecodable (no hang, no huge allocation)
+    with open(os.path.join(tmp_path, "env.hdr"), "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 8 +X 16\n" + bytes([2, 2, 0, 16, 0]))
+    with open(os.path.join(tmp_path, "neg.hdr"), "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y -8 +X 16\n")
+    for fn in ("env.hdr", "neg.hdr"):
+        sc3 = dict(sc); sc3["light_sampler"] = {"type": "uniform", "param": {"lights": [{"type": "spherical", "param": {"color": {"fn": fn, "color_space": "linear"}, "scale": 1}}]}}
+        path = os.path.join(tmp_path, fn + ".json"); json.dump(sc3, open(path, "w"))
+        with pytest.raises(HostError, match="nor decodable"):
+            HostScene(path, width=16, height=16, procedural_env=False)

@@ -4,7 +4,7 @@
 for lib in vision_amd/lib/exp/libvmk_*.so; do
   [ -f "$lib" ] || continue
   echo "== $lib"
-  out=$(VMK_LIB=$lib timeout -k 5 90 python tools/gpu_diag_matte.py 2>&1) || { echo "$out" | tail -3; echo "diag failed"; continue; }
+  out=$(VMK_LIB=$lib timeout -k 5 90 python tests/diag_matte.py 2>&1) || { echo "$out" | tail -3; echo "diag failed"; continue; }
   echo "$out" | head -3
   if echo "$out" | grep -q "mismatching pixels 0 of"; then
     VMK_LIB=$lib timeout -k 5 200 python tools/gpu_selfcheck.py 2>&1 | tail -8 || { echo "selfcheck killed"; exit 1; }

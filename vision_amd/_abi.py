@@ -106,7 +106,8 @@ class AccelInfo(C.Structure):
 
 class HostOptions(C.Structure):
     _fields_ = [("width", u32), ("height", u32), ("max_depth", i32), ("min_depth", i32), ("procedural_env", u32),
-                ("drop_unsupported_lights", u32), ("lut_path", C.c_char_p), ("mediums", u32), ("spectrum", u32)]
+                ("drop_unsupported_lights", u32), ("lut_path", C.c_char_p), ("mediums", u32), ("spectrum", u32),
+                ("missing_assets", u32)]
 
 
 # every symbol include/vmk.h declares (checked by tests/test_abi.py without a GPU)

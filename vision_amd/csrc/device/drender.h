@@ -375,6 +375,44 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// unit kernel: the whole path of one (pixel, frame) stepped vertex by vertex with path_bounce<true, true>, one lane per path
+// and no persistent loop — a second, independently compiled instance of the path code (its own register budget), which
+// vmk_self_check compares bit for bit with the megakernel variant a scene selects, and which the parity tests compare with
+// the oracle's path records.  Output: 8 floats per vertex for the first 8 vertices, then L (o[64..66]).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kUnitPathVertexCap = 1 << 16; // a safety net far above anything a real path reaches (k_render has no cap either)
+__device__ __forceinline__ void unit_path(const DScene &S, const vmk_render_params *P, WaveScratch *ws, bool live, uint32_t px, uint32_t py, uint32_t frame, float *o, DCounters &cnt) {
+    Sampler smp; smp.start(px, py, frame, 0);
+    PathState ps; ps.ray = generate_ray(P, px, py, smp);
+#if VMK_HERO
+    smp.start(px, py, frame, 0xFFFFFFFFu); // RenderEnv::initial
+    ps.swl = sample_wavelengths(smp);
+#endif
+    smp.start(px, py, frame, 1);
+    path_begin(ps, P);
+    bool alive = live;
+    for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
+        float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int st = path_bounce<true, true>(S, P, ws, ps, smp, cnt, dbg, alive);
+        if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
+        if (st == kPathTail && alive) st = tail_is_primary(P, px, py, frame, ps.ray.d) ? kPathEnd : kPathGoOn;
+        if (st != kPathGoOn) alive = false;
+    }
+    if (live) { o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z; }
+}
+// in: 3 uint32 (px, py, frame) per path; out: >= 67 floats per path; launched with 64-thread blocks
+__global__ void k_unit_path(const DScene *scene, const vmk_render_params *P, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
+    __shared__ WaveScratch s_ws[1];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const float *a = in + (size_t) (live ? i : 0) * in_stride;
+    float *o = out + (size_t) (live ? i : 0) * out_stride;
+    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+    const DScene S = *scene;
+    unit_path(S, P, s_ws, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
+}
+
 // the eight ahead-of-time variants
 typedef void (*RenderKernel)(RenderArgs);
 inline RenderKernel select_render_kernel(bool full, bool media, bool count) {

@@ -27,6 +27,7 @@ using namespace vmkd;
 
 // the hero-spectrum instance of the megakernel lives in vmk_hero.hip
 hipError_t vmk_hero_occupancy(bool full, bool media, bool count, int *blocks_per_cu);
+hipError_t vmk_hero_launch_unit_path(hipStream_t stream, const void *scene, const void *params, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride);
 hipError_t vmk_hero_launch_render(bool full, bool media, bool count, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
 
 #define HIP_TRY(expr)                                                                                          \
@@ -291,9 +292,6 @@ __global__ void k_tonemap(const float4 *accum, float4 *out, uint32_t n, float ex
     out[i] = make_float4(v[0], v[1], v[2], 1.f);
 }
 
-// The unit kernel steps a path until it ends, like k_render (which is bounded by max_depth and the scene's geometry only:
-// pass-through vertices are not counted as bounces); the cap is a safety net far above anything a real path reaches.
-constexpr int kUnitPathVertexCap = 1 << 16;
 __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
     __shared__ WaveScratch s_ws[1]; // launched with 64-thread blocks
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,20 +347,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
         }
         case 6: { // whole path of one (pixel, frame): 8 floats per vertex for up to 8 vertices, then L (3 floats)
             const DScene S = *scene;
-            uint32_t px = f2u(a[0]), py = f2u(a[1]), frame = f2u(a[2]);
-            Sampler smp; smp.start(px, py, frame, 0);
-            PathState ps; ps.ray = generate_ray(P, px, py, smp);
-            smp.start(px, py, frame, 1);
-            path_begin(ps, P);
-            bool alive = live;
-            for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
-                float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                int st = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
-                if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
-                if (st == kPathTail && alive) st = tail_is_primary(P, px, py, frame, ps.ray.d) ? kPathEnd : kPathGoOn;
-                if (st != kPathGoOn) alive = false;
-            }
-            if (live) { o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z; }
+            unit_path(S, P, s_ws, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
             break;
         }
 #ifdef VMK_DIAG
@@ -1401,7 +1386,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     if ((kind == 6 || kind == 7) && ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_test_eval: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     if ((kind == 6 || kind == 7) && ctx->params.process_mediums && ctx->params.camera_medium != VMK_INVALID && ctx->params.camera_medium >= ctx->n_mediums) { ctx->error = "vmk_test_eval: camera medium out of range"; return VMK_ERR_ARG; }
     if (kind == 5 && !ctx->params_ready) { ctx->error = "vmk_test_eval: kind 5 needs render params"; return VMK_ERR_STATE; }
-    if ((kind == 4 || kind == 6 || kind == 7) && ctx->hero) { ctx->error = "vmk_test_eval: the material / path unit kernels are the sRGB instance; a hero-spectrum scene is uploaded"; return VMK_ERR_UNSUPPORTED; }
+    if ((kind == 4 || kind == 7) && ctx->hero) { ctx->error = "vmk_test_eval: the material unit kernel and the ray capture are the sRGB instance; a hero-spectrum scene is uploaded (kind 6, the path unit kernel, exists for both)"; return VMK_ERR_UNSUPPORTED; }
     if (kind == 4) { // material ids are validated here: the kernel indexes materials[] with them
         uint32_t n_mat = (uint32_t) ctx->materials.n;
         for (uint32_t i = 0; i < n; ++i) { uint32_t id; std::memcpy(&id, in + (size_t) i * in_stride, 4); if (id >= n_mat) { ctx->error = "vmk_test_eval: material id out of range"; return VMK_ERR_ARG; } }
@@ -1415,8 +1400,11 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
 #ifdef VMK_DIAG
         kind = kind_arg;
 #endif
-        hipLaunchKernelGGL(k_test, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_scene.p, ctx->d_params.p, kind, n, di.p, in_stride, dout.p, out_stride);
-        e = hipGetLastError();
+        if (ctx->hero && kind == 6) e = vmk_hero_launch_unit_path(ctx->stream, ctx->d_scene.p, ctx->d_params.p, n, di.p, in_stride, dout.p, out_stride);
+        else {
+            hipLaunchKernelGGL(k_test, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_scene.p, ctx->d_params.p, kind, n, di.p, in_stride, dout.p, out_stride);
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, (size_t) n * out_stride * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1432,7 +1420,6 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
 int vmk_self_check(vmk_ctx *ctx, uint32_t max_pixels, uint32_t *n_checked, uint32_t *n_mismatch) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready || !ctx->fb) { ctx->error = "vmk_self_check: scene/accel/params not ready"; return VMK_ERR_STATE; }
-    if (ctx->hero) { ctx->error = "vmk_self_check: the unit kernel is the sRGB instance; a hero-spectrum scene is uploaded"; return VMK_ERR_UNSUPPORTED; }
     if (n_checked) *n_checked = 0;
     if (n_mismatch) *n_mismatch = 0;
     const uint32_t w = ctx->params.width, h = ctx->params.height;

@@ -27,3 +27,9 @@ hipError_t vmk_hero_launch_render(bool full, bool media, bool count, unsigned bl
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, A);
     return hipGetLastError();
 }
+// the hero instance of the path unit kernel (drender.h k_unit_path): vmk_test_eval kind 6 and vmk_self_check on hero scenes
+hipError_t vmk_hero_launch_unit_path(hipStream_t stream, const void *scene, const void *params, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
+    using namespace vmkd;
+    hipLaunchKernelGGL(k_unit_path, dim3((n + 63) / 64), dim3(64), 0, stream, (const DScene *) scene, (const vmk_render_params *) params, n, in, in_stride, out, out_stride);
+    return hipGetLastError();
+}

@@ -144,6 +144,7 @@ static bool load_hdr(const std::string &path, Image &img) {
     std::getline(f, line);
     int w = 0, h = 0;
     if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2) return false;
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return false; // malformed header: no allocation from it
     img.w = w; img.h = h; img.channels = 3; img.is_float = true; img.f32.assign((size_t) w * h * 4, 1.f);
     std::vector<uint8_t> scan((size_t) w * 4);
     for (int y = 0; y < h; ++y) {
@@ -154,13 +155,15 @@ static bool load_hdr(const std::string &path, Image &img) {
                 int x = 0;
                 while (x < w) {
                     uint8_t n; f.read((char *) &n, 1);
-                    if (n > 128) { uint8_t v; f.read((char *) &v, 1); n -= 128; while (n-- && x < w) scan[(size_t) x++ * 4 + c] = v; }
-                    else { while (n-- && x < w) { uint8_t v; f.read((char *) &v, 1); scan[(size_t) x++ * 4 + c] = v; } }
+                    if (!f || n == 0) return false; // truncated file / zero-length run: the loop would never advance
+                    if (n > 128) { uint8_t v; f.read((char *) &v, 1); if (!f) return false; n -= 128; while (n-- && x < w) scan[(size_t) x++ * 4 + c] = v; }
+                    else { while (n-- && x < w) { uint8_t v; f.read((char *) &v, 1); if (!f) return false; scan[(size_t) x++ * 4 + c] = v; } }
                 }
             }
         } else {
             std::memcpy(scan.data(), hd, 4);
             f.read((char *) scan.data() + 4, (std::streamsize) ((size_t) w * 4 - 4));
+            if (!f) return false;
         }
         for (int x = 0; x < w; ++x) {
             const uint8_t *p = &scan[(size_t) x * 4];
@@ -292,6 +295,10 @@ struct HostScene {
         if (reg != g_images.end()) img = &reg->second;
         else if (ends_with(fn, ".hdr") && load_hdr(path, local)) img = &local;
         else if (allow_procedural && opt.procedural_env) { procedural_sky(local); img = &local; describe("image", "procedural_sky", fn + " (stand-in: file missing)"); }
+        else if (opt.missing_assets == 1 && !file_exists(path)) { // declared stand-in for an asset stripped from the checkout: 1x1 mid-grey
+            local.w = local.h = 1; local.channels = 3; local.is_float = false; local.u8 = {128, 128, 128, 255};
+            img = &local; describe("image", "constant_grey", fn + " (stand-in: file missing)");
+        }
         else fail("image '" + path + "' is neither registered (vmk_host_register_image) nor decodable natively" + (file_exists(path) ? "" : " (file missing)"));
         vmk_texture t{};
         while (tex_data.size() % 16) tex_data.push_back(0);
@@ -572,7 +579,10 @@ struct HostScene {
                     while (*q == ' ' || *q == '\t' || *q == '\r') ++q;
                     if (!*q) break;
                     int vi = 0, ti = 0, ni = 0; char *e;
-                    vi = (int) std::strtol(q, &e, 10); q = e;
+                    if (*q == '#') break; // trailing comment
+                    vi = (int) std::strtol(q, &e, 10);
+                    if (e == q) fail("malformed face record in '" + path + "': '" + line + "'"); // strtol consumed nothing: no progress
+                    q = e;
                     if (*q == '/') { ++q; if (*q != '/') { ti = (int) std::strtol(q, &e, 10); q = e; } if (*q == '/') { ++q; ni = (int) std::strtol(q, &e, 10); q = e; } }
                     if (vi < 0) vi = (int) P.size() + vi + 1;
                     if (ti < 0) ti = (int) T.size() + ti + 1;
@@ -780,6 +790,10 @@ struct HostScene {
                 std::string fn = p["fn"].as_string();
                 if (p["swap_handed"].as_bool(false) || p["subdiv_level"].as_uint(0)) fail("shape/model swap_handed/subdiv_level are outside the hot-path scope");
                 if (!ends_with(fn, ".obj")) fail("shape/model: only Wavefront .obj is supported ('" + fn + "')");
+                if (!list_only && opt.missing_assets == 1 && !file_exists(join_path(scene_dir, fn))) { // stripped mesh: skipped, and said so
+                    describe("shape", "model_skipped", sd["name"].as_string() + " " + fn + " (stand-in: file missing, shape omitted)");
+                    continue;
+                }
                 mesh = list_only ? Mesh{} : load_obj(join_path(scene_dir, fn), p["flip_uv"].as_bool(true), p["smooth"].as_bool(false));
             } else fail("shape/" + type + " is outside the hot-path scope (quad/cube/model)");
             describe("shape", type, sd["name"].as_string());

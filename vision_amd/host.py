@@ -77,14 +77,14 @@ class HostScene:
     """Owns the host-side tables of one loaded scene (freed on close())."""
 
     def __init__(self, json_path, width=0, height=0, max_depth=-1, min_depth=-1, procedural_env=True,
-                 drop_unsupported_lights=False, lut_path=None, mediums=False, spectrum=None):
+                 drop_unsupported_lights=False, lut_path=None, mediums=False, spectrum=None, missing_assets=None):
         L = lib()
         json_path = os.path.abspath(json_path)
         self.json_path = json_path
         self.image_paths = register_images_for(json_path)
         opt = _abi.HostOptions(width, height, max_depth, min_depth, int(procedural_env), int(drop_unsupported_lights),
                                (lut_path or DEFAULT_LUT_PATH).encode(), int(mediums),
-                               {None: 0, "srgb": 1, "hero": 2}[spectrum])
+                               {None: 0, "srgb": 1, "hero": 2}[spectrum], {None: 0, "fail": 0, "standin": 1}[missing_assets])
         h = C.c_void_p()
         rc = L.vmk_host_load_scene(json_path.encode(), C.byref(opt), C.byref(h))
         if rc != 0:

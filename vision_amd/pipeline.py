@@ -93,10 +93,11 @@ class Pipeline:
     """pipeline/fixed.  `Pipeline(scene_json)` plays Importer::import_scene + init_scene."""
 
     def __init__(self, scene_file, device=0, width=0, height=0, max_depth=-1, min_depth=-1, procedural_env=True,
-                 drop_unsupported_lights=False, mediums=False, spectrum=None):
+                 drop_unsupported_lights=False, mediums=False, spectrum=None, missing_assets=None):
         # every option of the scene load is kept: change_resolution re-derives the tables with the same ones
         self._host_options = dict(max_depth=max_depth, min_depth=min_depth, procedural_env=procedural_env,
-                                  drop_unsupported_lights=drop_unsupported_lights, mediums=mediums, spectrum=spectrum)
+                                  drop_unsupported_lights=drop_unsupported_lights, mediums=mediums, spectrum=spectrum,
+                                  missing_assets=missing_assets)
         self.host_scene = HostScene(scene_file, width=width, height=height, **self._host_options)
         self.params = self.host_scene.params_copy()
         self.backend = Backend(device)
