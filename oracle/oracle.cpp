@@ -1788,6 +1788,7 @@ int orc_render_aov(void *h, const vmk_render_params *p, const float *w2c, const 
 }
 
 void orc_reset_counters(void *h) {
+    tl_cnt = LocalCounters{}; // tallies a previous orc_test_eval / orc_trace_rays left on the calling thread
     Counters &c = ((orc_scene_handle *) h)->sv.cnt;
     c.closest = 0; c.shadow = 0; c.nodes = 0; c.tris = 0; c.paths = 0; c.hits = 0; c.tex = 0;
 }

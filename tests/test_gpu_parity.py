@@ -121,10 +121,6 @@ def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     # the megakernel variant this scene selects agrees with the unit kernel (vmk_self_check); hero scenes have their own
     # instance of the path unit kernel (vmk_hero.hip k_unit_path)
     assert backend.self_check() == w * h
-    if hero:  # ... which also reproduces the oracle's per-vertex path records
-        yy, xx = np.mgrid[0:h, 0:w]
-        pix6 = np.stack([xx.ravel(), yy.ravel(), np.full(w * h, 1)], 1).astype(np.uint32).view(np.float32)
-        assert _bits_equal(backend.test_eval(6, pix6, 67), osc.test_eval(p, 6, pix6, 67))
     backend.reset_accum(); backend.reset_counters()
     backend.render_batch(0, spp)
     img = backend.download_accum()
@@ -137,6 +133,10 @@ def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     for k in ("closest_rays", "shadow_rays", "paths", "surface_hits"):
         assert cg[k] == co[k], (k, cg[k], co[k])
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "not bit-exact (within tolerance, but the build is designed to be exact)"
+    if hero:  # the hero unit kernel also reproduces the oracle's per-vertex path records
+        yy, xx = np.mgrid[0:h, 0:w]
+        pix6 = np.stack([xx.ravel(), yy.ravel(), np.full(w * h, 1)], 1).astype(np.uint32).view(np.float32)
+        assert _bits_equal(backend.test_eval(6, pix6, 67), osc.test_eval(p, 6, pix6, 67))
 
 
 def test_config1_cbox_1024x1024_matches_oracle_on_sampled_tiles(backend):
@@ -532,7 +532,8 @@ def test_config5_bathroom2_4k_sampled_tiles_and_eight_emulated_ranks(backend):
     (3) no rank is pinned to a column set at 3840 px (120 tiles per row = 15 x 8)."""
     from vision_amd import _abi
     hs, p, osc, info = _load(backend, "scenes/bathroom2/vision_scene.json", 3840, 2160, missing_assets="standin", max_depth=64)
-    assert p.max_depth == 64 and hs.scene.n_tris > 380000 and info["depth"] <= info["stack_depth"]
+    assert p.max_depth == 64 and hs.scene.n_tris > 380000
+    assert info["depth"] > info["stack_depth"]  # PLOC's tree needs 94 stack entries: the deep-tree kernel variants (HBM stack overflow) serve it
     assert hs.description.count("stand-in") == 12
     assert backend.self_check() > 4000
     backend.reset_accum(); backend.reset_counters()

@@ -19,6 +19,11 @@ namespace vmkd {
 #define VMK_QUAD_STACK 64
 #endif
 constexpr int kQuadStack = VMK_QUAD_STACK; // stack entries per ray; a build whose worst-case need exceeds it is rejected
+// Trees deeper than that (bathroom2's PLOC tree needs 94) keep the entries beyond the LDS stack in HBM (DScene::stack_overflow):
+// every lane of the quad writes and reads ITS OWN copy of the quad's overflow entries ([entry][lane], 256 B coalesced per entry), so
+// no value crosses lanes through global memory — the refs of the other three lanes come over DPP in the (cold) overflow branch.
+constexpr int kStackOverflow = 192;      // entries per ray beyond kQuadStack
+constexpr uint32_t kOverflowWaves = 8192; // waves of one grid the overflow area serves (persistent grids use <= 6144)
 constexpr int32_t kTravDone = 0x7fffffff;
 
 struct Hit { uint32_t inst, prim, tri; V2 bary; };
@@ -157,7 +162,9 @@ struct GlobalRayIO {
 // COUNT: tally node fetches and triangle tests (cnt.nodes / cnt.tris, the algorithmic-bytes side of the roofline); the two adds sit
 // in the innermost loops, so timed launches can run the COUNT = false instance and take the tallies from a sibling launch over
 // the same (deterministic) rays.
-template<class IO, bool COUNT = true>
+// DEEP: the tree's worst-case stack need exceeds the LDS stack — entries beyond it live in HBM (see kStackOverflow).  A compile-time
+// variant: the test on every push / pop costs the hot kernel 8 % on classroom when it is there unconditionally.
+template<class IO, bool COUNT = true, bool DEEP = false>
 VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, uint32_t *n_rays) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
     // ---- per-quad traversal state, replicated in the quad's 4 lanes ----
@@ -173,7 +180,9 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
     uint32_t binst = VMK_INVALID, bprim = VMK_INVALID, btri = VMK_INVALID;
     bool found = false;
     uint32_t nn = 0, nt = 0, nr = 0;
-#define VMK_POP() do { if (sp > 0) { --sp; cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
+    // this wave's slice of the HBM stack overflow (null unless the tree needs it)
+    uint32_t *const ovf = (DEEP && S.stack_overflow) ? S.stack_overflow + ((size_t) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kStackOverflow) * 64u + lane : nullptr;
+#define VMK_POP() do { if (sp > 0) { --sp; if constexpr (DEEP) cur = sp < kQuadStack ? (int32_t) ws->stack[sp][quad] : (int32_t) ovf[(size_t) (sp - kQuadStack) * 64u]; else cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
 
     for (;;) {
         // ================= node phase =================
@@ -210,13 +219,27 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                     int slot = sp + (n - 1 - rank);
                     if (slot < kQuadStack) ws->stack[slot][quad] = (uint32_t) ref;
                 }
+                if constexpr (DEEP) if (sp + n - 1 > kQuadStack && ovf) { // cold: some of the far children land beyond the LDS stack (deep trees only)
+                    const int32_t r1 = quad_perm_i<kQuadXor1>(ref), r2 = quad_perm_i<kQuadXor2>(ref), r3 = quad_perm_i<kQuadXor3>(ref);
+                    const uint32_t kk[4] = {key, k1, k2, k3};
+                    const int32_t rr[4] = {ref, r1, r2, r3};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { // every member of the quad, as seen from this lane
+                        if (kk[j] == 0xffffffffu) continue;
+                        int rank_j = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rank_j += kk[i] < kk[j] ? 1 : 0;
+                        const int slot_j = sp + (n - 1 - rank_j);
+                        if (rank_j > 0 && slot_j >= kQuadStack && slot_j < kQuadStack + kStackOverflow) ovf[(size_t) (slot_j - kQuadStack) * 64u] = (uint32_t) rr[j];
+                    }
+                }
                 // The pops below read entries that OTHER lanes of the quad have just written.  The hardware keeps the LDS
                 // operations of a wave in issue order, so all that is needed is that every lane's store is ISSUED before
                 // any lane's load: a convergent fence between the two, which the compiler may neither duplicate into the
                 // divergent `if` above nor sink loads across (no instruction is emitted for it).  Without it the order of
                 // the two was a property of the block layout the optimiser happened to pick ("UB").
                 wave_lds_fence();
-                if (n > 0) { cur = cand; sp = min(sp + n - 1, kQuadStack); }
+                if (n > 0) { cur = cand; sp = min(sp + n - 1, (DEEP && ovf) ? kQuadStack + kStackOverflow : kQuadStack); }
                 else VMK_POP();
                 if (cur < 0 && pend == kTravDone) { pend = cur; VMK_POP(); } // park the leaf, keep descending
             }
@@ -289,7 +312,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
 // Trace the rays of all lanes of the wave.  EVERY lane of the wave must call this (convergently); `active` says whether
 // the lane has a ray.  any_hit rays stop at the first valid hit (occlusion query), the others return the closest hit.
 // Returns found; `hit` is filled for closest-hit rays.
-template<bool COUNT = true>
+template<bool COUNT = true, bool DEEP = false>
 VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, WaveScratch *ws, Hit &hit, DCounters &cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
@@ -305,7 +328,7 @@ VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, 
     }
     wave_lds_fence();
     LdsRayIO io = {ws, n_act, 0};
-    traverse_core<LdsRayIO, COUNT>(S, io, ws, cnt, nullptr);
+    traverse_core<LdsRayIO, COUNT, DEEP>(S, io, ws, cnt, nullptr);
     wave_lds_fence();
     bool res = false;
     if (active) {

@@ -74,7 +74,7 @@ VD V3 hg_sample(V3 wo, float g, Sampler &sampler, float *f_out) { // 2 draws
 // `dbg` (tests / ray capture only): 16 floats per vertex —
 // [hit inst, prim, bary.xy | light pdf, bsdf pdf towards the light, sampled pdf, occluded | shadow ray o.xyz d.xyz t_max, traced].
 enum : int { kPathGoOn = 0, kPathEnd = 1, kPathTail = 2 };
-template<bool FULL, bool MEDIA, bool COUNT = true>
+template<bool FULL, bool MEDIA, bool COUNT = true, bool DEEP = false>
 __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_params *P, WaveScratch *ws, PathState &ps, Sampler &sampler,
                                            DCounters &cnt, float *dbg, bool active) {
     const uint32_t max_depth = P->max_depth, min_depth = P->min_depth, mis_mode = P->mis_mode;
@@ -85,7 +85,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
     const bool tail = ps.bounces >= max_depth; // the supplement pass (see above)
     Hit hit;
     if (active) cnt.closest++;
-    bool found = traverse_wave<COUNT>(S, ps.ray, active, false, ws, hit, cnt);
+    bool found = traverse_wave<COUNT, DEEP>(S, ps.ray, active, false, ws, hit, cnt);
     if (dbg && active) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
     bool shade = false; // the lane reached a surface with a material: NEE + scattering follow
     Interaction it;
@@ -160,7 +160,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
         }
     }
     Hit sh;
-    bool occluded = traverse_wave<COUNT>(S, shadow_ray, shade, true, ws, sh, cnt);
+    bool occluded = traverse_wave<COUNT, DEEP>(S, shadow_ray, shade, true, ws, sh, cnt);
     if (!shade) return pass_through ? kPathGoOn : kPathEnd;
     V3 tr_shadow = mk3(1.f);
     if constexpr (MEDIA) tr_shadow = geometry_Tr(S, P, shadow_ray, P->process_mediums ? (dot(it.ng, shadow_ray.d) > 0.f ? med_out : med_in) : VMK_INVALID SWL_A);
@@ -272,7 +272,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderRest &A, uint32_t slot
 // All four <FULL, MEDIA> variants run at the same waves/SIMD.  (Round 1 pinned the MEDIA variants to 4 after a
 // k_render<true, true> at 96 registers disagreed with the unit kernel; the cause turned out to be the SLP-vectoriser
 // miscompile described in DESIGN.md section 8, which the build now avoids with -fno-slp-vectorize.)
-template<bool FULL, bool MEDIA, bool COUNT>
+template<bool FULL, bool MEDIA, bool COUNT, bool DEEP>
 __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVES_PER_SIMD) void k_render(RenderArgs A) {
     __shared__ WaveScratch s_ws[kBlock / 64];
     const DScene S = A.scene;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
         // (all lanes take part: the traversals inside are wave-cooperative; lanes without a path contribute no ray)
 #ifdef VMK_DIAG
         float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int state = path_bounce<FULL, MEDIA, COUNT>(S, P, ws, ps, sampler, cnt, dbg, has_path);
+        int state = path_bounce<FULL, MEDIA, COUNT, DEEP>(S, P, ws, ps, sampler, cnt, dbg, has_path);
         if (has_path && diag_verts < 8u && A.diag) {
             float *q = A.diag + ((size_t) item * 8u + diag_verts) * 16u;
             for (int k = 0; k < 16; ++k) q[k] = dbg[k];
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
             q[15] = u2f(sampler.state);
         }
 #else
-        int state = path_bounce<FULL, MEDIA, COUNT>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
+        int state = path_bounce<FULL, MEDIA, COUNT, DEEP>(S, P, ws, ps, sampler, cnt, nullptr, has_path);
 #endif
         if (state == kPathTail && has_path) { // max_depth < 2 only (uniform per launch)
             uint32_t f = item / A.n_slots, px, py;
@@ -394,7 +394,7 @@ __device__ __forceinline__ void unit_path(const DScene &S, const vmk_render_para
     bool alive = live;
     for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
         float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int st = path_bounce<true, true>(S, P, ws, ps, smp, cnt, dbg, alive);
+        int st = path_bounce<true, true, true, true>(S, P, ws, ps, smp, cnt, dbg, alive); // (DEEP: the unit kernel serves every tree)
         if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
         if (st == kPathTail && alive) st = tail_is_primary(P, px, py, frame, ps.ray.d) ? kPathEnd : kPathGoOn;
         if (st != kPathGoOn) alive = false;
@@ -413,11 +413,13 @@ __global__ void k_unit_path(const DScene *scene, const vmk_render_params *P, uin
     unit_path(S, P, s_ws, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
 }
 
-// the eight ahead-of-time variants
+// the twelve ahead-of-time variants: <FULL, MEDIA> x {tallying, not tallying} for trees that fit the LDS stack, and the tallying
+// <FULL, MEDIA> instances with the HBM stack overflow for deep trees
 typedef void (*RenderKernel)(RenderArgs);
-inline RenderKernel select_render_kernel(bool full, bool media, bool count) {
-    if (count) return full ? (media ? k_render<true, true, true> : k_render<true, false, true>) : (media ? k_render<false, true, true> : k_render<false, false, true>);
-    return full ? (media ? k_render<true, true, false> : k_render<true, false, false>) : (media ? k_render<false, true, false> : k_render<false, false, false>);
+inline RenderKernel select_render_kernel(bool full, bool media, bool count, bool deep) {
+    if (deep) return full ? (media ? k_render<true, true, true, true> : k_render<true, false, true, true>) : (media ? k_render<false, true, true, true> : k_render<false, false, true, true>);
+    if (count) return full ? (media ? k_render<true, true, true, false> : k_render<true, false, true, false>) : (media ? k_render<false, true, true, false> : k_render<false, false, true, false>);
+    return full ? (media ? k_render<true, true, false, false> : k_render<true, false, false, false>) : (media ? k_render<false, true, false, false> : k_render<false, false, false, false>);
 }
 
 }// namespace vmkd

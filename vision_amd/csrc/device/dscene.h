@@ -43,6 +43,9 @@ struct DSceneBase {
     uint32_t n_tris, n_lights, env_light;
     uint32_t light_alias_offset; // lightsampler/power table (VMK_INVALID when absent)
     float light_alias_integral;
+    // Deep trees only (worst-case traversal stack need > the LDS stack, dbvh.h kQuadStack): HBM overflow of the per-ray stacks,
+    // [wave of the grid][entry beyond the LDS stack][lane]; null otherwise.
+    uint32_t *stack_overflow;
 };
 // hero spectrum only: sRGB uplift table float4[3][64][64][64], tabulated-spectra pool, CIE x, y, z, D65 (vmk_scene)
 struct DSceneHero {

@@ -26,9 +26,9 @@
 using namespace vmkd;
 
 // the hero-spectrum instance of the megakernel lives in vmk_hero.hip
-hipError_t vmk_hero_occupancy(bool full, bool media, bool count, int *blocks_per_cu);
+hipError_t vmk_hero_occupancy(bool full, bool media, bool count, bool deep, int *blocks_per_cu);
 hipError_t vmk_hero_launch_unit_path(hipStream_t stream, const void *scene, const void *params, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride);
-hipError_t vmk_hero_launch_render(bool full, bool media, bool count, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
+hipError_t vmk_hero_launch_render(bool full, bool media, bool count, bool deep, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -254,6 +254,7 @@ __global__ void k_film_resolve(RenderRest A) {
 // ---------------------------------------------------------------------------------------------------------
 // traversal replay, tone map, unit tests
 // ---------------------------------------------------------------------------------------------------------
+template<bool DEEP>
 __global__ __launch_bounds__(kBlock) void k_trace(const DScene S, uint32_t n, const float *org, const float *dir, const float *tmax,
                                                   int any_hit, uint32_t *hit_out, unsigned long long *counters, uint32_t *queue, uint32_t chunk) {
     __shared__ WaveScratch s_ws[kBlock / 64];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const DScene S, uint32_t n, co
     uint32_t n_rays = 0;
     if (S.n_tris == 0) { // nothing to hit
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { io.store((int) i, false, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); ++n_rays; }
-    } else traverse_core<GlobalRayIO, true>(S, io, ws, cnt, &n_rays);
+    } else traverse_core<GlobalRayIO, true, DEEP>(S, io, ws, cnt, &n_rays);
     if (any_hit) cnt.shadow += n_rays; else cnt.closest += n_rays;
     uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
     for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
@@ -383,7 +384,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) {
                 float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 Ray r = ps.ray;
-                int st = path_bounce<true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
+                int st = path_bounce<true, true, true, true>(S, P, s_ws, ps, smp, cnt, dbg, alive);
                 if (alive && v < 24) {
                     float *q = o + 1 + v * 16;
                     q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = r.t_max; q[7] = 1.f;
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
         V2 p_film;
         Ray ray = generate_ray(P, px, py, sampler, &p_film);
         Hit hit;
-        bool found = traverse_wave(S, ray, live, false, ws, hit, cnt);
+        bool found = traverse_wave<true, true>(S, ray, live, false, ws, hit, cnt); // (DEEP: serves every tree)
         if (!live) continue;
         V3 normal = mk3(0.f), albedo = mk3(0.f), emission = mk3(0.f);
         float depth = 0.f;
@@ -567,6 +568,7 @@ struct vmk_ctx {
     DevBuf<float> alias_prob, alias_func, srgb_lut, luts;
     DevBuf<uint32_t> alias_idx;
     DevBuf<BvhNode> nodes;
+    DevBuf<uint32_t> stack_overflow; // only for trees deeper than the LDS stack
     DevBuf<DSceneFull> d_scene; // DSceneBase prefix + hero tail (dscene.h)
     DSceneFull h_scene{};
     float world_min[3]{}, world_max[3]{};
@@ -693,7 +695,7 @@ void vmk_destroy(vmk_ctx *ctx) {
     ctx->tri_pos_in.release(); ctx->tri_pos.release(); ctx->tri_attr_in.release(); ctx->tri_attr.release(); ctx->tri_lookup.release();
     ctx->instances.release(); ctx->materials.release(); ctx->lights.release(); ctx->mediums.release(); ctx->textures.release(); ctx->tex_data.release();
     ctx->alias_prob.release(); ctx->alias_func.release(); ctx->alias_idx.release(); ctx->srgb_lut.release(); ctx->luts.release(); ctx->rgb2spec.release(); ctx->spd.release();
-    ctx->nodes.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release(); ctx->stage.release();
+    ctx->nodes.release(); ctx->stack_overflow.release(); ctx->d_scene.release(); ctx->d_params.release(); ctx->own_fb.release(); ctx->tm_out.release(); ctx->stage.release();
     ctx->queue.release(); ctx->counters.release(); ctx->tile_table.release(); ctx->gather_send.release(); ctx->gather_recv.release();
     vmk_comm_release(ctx);
     for (auto &pr : ctx->time_pool) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
@@ -932,9 +934,12 @@ int vmk_build_accel(vmk_ctx *ctx) {
 #undef BUILD_TRY
     if (h_nodes > n_int) { ctx->error = "vmk_build_accel: BVH4 node count exceeds the allocation"; return VMK_ERR_STATE; }
     if ((uint64_t) h_nodes * sizeof(BvhNode) > 0xffffffffull) { ctx->error = "vmk_build_accel: node array exceeds the 4 GiB the traversal's 32-bit node offsets address"; return VMK_ERR_UNSUPPORTED; }
-    if (h_scalars[0] > kQuadStack) { ctx->error = "vmk_build_accel: worst-case traversal stack need " + std::to_string(h_scalars[0]) + " exceeds the per-ray LDS stack (" + std::to_string(kQuadStack) + ")"; return VMK_ERR_UNSUPPORTED; }
+    if (h_scalars[0] > kQuadStack + kStackOverflow) { ctx->error = "vmk_build_accel: worst-case traversal stack need " + std::to_string(h_scalars[0]) + " exceeds the per-ray stack (" + std::to_string(kQuadStack) + " entries in LDS + " + std::to_string(kStackOverflow) + " in HBM)"; return VMK_ERR_UNSUPPORTED; }
+    ctx->stack_overflow.release();
+    if (h_scalars[0] > kQuadStack) HIP_TRY(ctx->stack_overflow.alloc((size_t) kOverflowWaves * kStackOverflow * 64)); // deep tree: HBM overflow of the LDS stacks (dbvh.h)
     DSceneFull &h = ctx->h_scene;
     h.tri_pos = ctx->tri_pos.p; h.tri_attr = ctx->tri_attr.p; h.tri_lookup = ctx->tri_lookup.p; h.nodes = ctx->nodes.p;
+    h.stack_overflow = ctx->stack_overflow.p;
     h.root = n <= (uint32_t) kMaxLeafTris ? (int32_t) ~((uint32_t) 0 | ((n - 1u) << 28)) : 0;
     HIP_TRY(ctx->d_scene.upload(&h, 1, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1038,8 +1043,9 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     int per_cu = 0;
     const bool media = ctx->params.process_mediums != 0;
     const bool count = ctx->count_traversal;
-    auto kernel = select_render_kernel(ctx->full_materials, media, count);
-    if (ctx->hero) HIP_TRY(vmk_hero_occupancy(ctx->full_materials, media, count, &per_cu));
+    const bool deep = ctx->stack_overflow.p != nullptr;
+    auto kernel = select_render_kernel(ctx->full_materials, media, count, deep);
+    if (ctx->hero) HIP_TRY(vmk_hero_occupancy(ctx->full_materials, media, count, deep, &per_cu));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1067,7 +1073,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         HIP_TRY(hipMemsetAsync(ctx->diag.p, 0, (size_t) n_items * 128 * 4, ctx->stream));
         A.diag = ctx->hero ? nullptr : ctx->diag.p;
 #endif
-        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, count, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
+        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, count, deep, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
         else {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
             HIP_TRY(hipGetLastError());
@@ -1282,7 +1288,8 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     (void) hipEventRecord(ctx->ev0, ctx->stream);
     for (uint32_t r = 0; r < repeats; ++r) {
         (void) hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream);
-        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, ctx->stream, static_cast<const DScene &>(ctx->h_scene), n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
+        if (ctx->stack_overflow.p) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, static_cast<const DScene &>(ctx->h_scene), n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
+        else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, static_cast<const DScene &>(ctx->h_scene), n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
     }
     (void) hipEventRecord(ctx->ev1, ctx->stream);
     e = hipMemcpyAsync(hit_out, h.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream);
@@ -1383,6 +1390,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
     if (in_stride < min_in[kind] || out_stride < min_out[kind]) { ctx->error = "vmk_test_eval: stride too small for this kind"; return VMK_ERR_ARG; }
     if (kind == 4 && !ctx->accel_ready) { ctx->error = "vmk_test_eval: kind 4 needs an uploaded scene + accel"; return VMK_ERR_STATE; }
     if ((kind == 6 || kind == 7) && (!ctx->accel_ready || !ctx->params_ready)) { ctx->error = "vmk_test_eval: kinds 6/7 need scene, accel and render params"; return VMK_ERR_STATE; }
+    if ((kind == 6 || kind == 7) && ctx->stack_overflow.p && (n + 63) / 64 > kOverflowWaves) { ctx->error = "vmk_test_eval: too many paths for one launch on a scene whose tree uses the HBM stack overflow"; return VMK_ERR_ARG; }
     if ((kind == 6 || kind == 7) && ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_test_eval: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     if ((kind == 6 || kind == 7) && ctx->params.process_mediums && ctx->params.camera_medium != VMK_INVALID && ctx->params.camera_medium >= ctx->n_mediums) { ctx->error = "vmk_test_eval: camera medium out of range"; return VMK_ERR_ARG; }
     if (kind == 5 && !ctx->params_ready) { ctx->error = "vmk_test_eval: kind 5 needs render params"; return VMK_ERR_STATE; }

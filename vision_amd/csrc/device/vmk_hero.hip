@@ -10,20 +10,20 @@
 
 #include <cstring>
 
-hipError_t vmk_hero_occupancy(bool full, bool media, bool count, int *blocks_per_cu) {
+hipError_t vmk_hero_occupancy(bool full, bool media, bool count, bool deep, int *blocks_per_cu) {
     using namespace vmkd;
-    auto kernel = select_render_kernel(full, media, count);
+    auto kernel = select_render_kernel(full, media, count, deep);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, kBlock, 0);
 }
 // Launch k_render<FULL, MEDIA> of the hero instance.  `rest` points at vmk.hip's RenderRest, `scene` at its DSceneFull (same
 // declarations, same layouts: only the namespace differs).
-hipError_t vmk_hero_launch_render(bool full, bool media, bool count, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes) {
+hipError_t vmk_hero_launch_render(bool full, bool media, bool count, bool deep, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes) {
     using namespace vmkd;
     RenderArgs A;
     if (rest_bytes != sizeof(RenderRest) || scene_bytes != sizeof(DScene)) return hipErrorInvalidValue;
     std::memcpy(static_cast<RenderRest *>(&A), rest, sizeof(RenderRest));
     std::memcpy(&A.scene, scene, sizeof(DScene));
-    auto kernel = select_render_kernel(full, media, count);
+    auto kernel = select_render_kernel(full, media, count, deep);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, A);
     return hipGetLastError();
 }
