@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VMK_ABI_VERSION 4u
+#define VMK_ABI_VERSION 5u
 #define VMK_INVALID 0xFFFFFFFFu
 
 typedef enum vmk_status {
@@ -82,6 +82,7 @@ enum { /* principled slot indices, principled_bsdf.cpp:235-256 */
 #define VMK_MATF_REMAP_ROUGHNESS 1u /* desc["remapping_roughness"] (default true) */
 #define VMK_MATF_HAS_SIGMA 2u       /* diffuse: Oren-Nayar when "sigma" present (diffuse.cpp:24-27) */
 #define VMK_MATF_DISPERSIVE 4u      /* glass, hero spectrum: the ior slot is an "spd" node (GlassMaterial::is_dispersive glass.cpp:234) */
+#define VMK_MATF_HAS_NORMAL 8u      /* desc.has_attr("normal") (material.cpp:312-316): vmk_material::normal feeds compute_shading_frame */
 
 /* A material / light parameter slot (ShaderNodeSlot, src/base/shader_graph/shader_node.cpp:242-273).
  * tex == VMK_INVALID : constant, value v[0..2] (scalar slots use v[0]).
@@ -106,8 +107,10 @@ typedef enum vmk_spectrum_type {
 typedef struct vmk_material {
     uint32_t type;  /* vmk_material_type */
     uint32_t flags; /* VMK_MATF_* */
-    uint32_t child0, child1; /* mix / add only: indices into materials[] (single-lobe types) */
+    uint32_t child0, child1; /* mix / add only: indices into materials[]: single-lobe types, or ONE principled_bsdf next to a
+                              * single-lobe type (LobeSet::flatten lobe.cpp:534-562 merges its lobes into the parent's list) */
     vmk_slot slot[VMK_MAX_SLOTS];
+    vmk_slot normal; /* VMK_MATF_HAS_NORMAL: tangent-space normal (Material::compute_shading_frame material.cpp:331-353) */
 } vmk_material;
 
 typedef enum vmk_light_type {

@@ -980,6 +980,37 @@ inline float layering_weight_max(float3 layer_albedo, float3 weight) { // princi
 inline float3 layering_weight(float3 layer_albedo, float3 weight) {
     return weight * saturate_(1.f - layering_weight_max(layer_albedo, weight));
 }
+// Material::compute_shading_frame (material.cpp:331-353) with detail::clamp_ns (:305-310) and PartialDerivative::update(n, s)
+// (interaction.h:106-112).  The normal slot's value is used as it comes (no 2x-1 remap in the reference), the rotation
+// that takes (0,0,1) to it is applied to the WORLD shading normal (as the reference writes it).  Quaternion::from_axis_angle /
+// to_float3x3 live in the absent ocarina layer: restated as Rodrigues' rotation about normalize(axis) — parity unpinned (App. B).
+inline float3 clamp_ns(float3 ns, float3 ng, float3 w) {
+    float3 w_refl = reflect(w, ns);
+    float3 w_refl_clip = same_hemisphere(w, w_refl, ng) ? w_refl : normalize(w_refl - ng * dot(w_refl, ng));
+    return normalize(w_refl_clip + w);
+}
+inline Frame compute_shading_frame(const vmk_scene *s, const vmk_material &m, const Interaction &it) {
+    Frame ret = it.shading;
+    if (!(m.flags & VMK_MATF_HAS_NORMAL)) return ret;
+    float3 normal = eval_slot3(s, m.normal, it.uv);
+    float3 n = make_float3(0.f, 0.f, 1.f);
+    float3 axis = cross(n, normal);
+    float theta = acos_(clamp_(dot(n, normal), -1.f, 1.f));
+    float3 world_normal = ret.z;
+    float len = length(axis);
+    if (len > 0.f) { // rotate ret.z about k = axis / |axis| by theta
+        float3 k = axis / len;
+        float st, ct; sincos_(theta, &st, &ct);
+        world_normal = ret.z * ct + cross(k, ret.z) * st + k * (dot(k, ret.z) * (1.f - ct));
+    }
+    world_normal = normalize(world_normal);
+    world_normal = clamp_ns(world_normal, it.ng, it.wo);
+    world_normal = normalize(face_forward(world_normal, it.shading.z));
+    float3 ss = normalize(ret.x - world_normal * dot(world_normal, ret.x));
+    float3 tt = normalize(cross(world_normal, ss));
+    ret.z = world_normal; ret.x = ss; ret.y = tt;
+    return ret;
+}
 inline void microfacet_alpha(const vmk_scene *s, const vmk_material &m, int slot_r, int slot_a, float2 uv, float rmin,
                              float *ax, float *ay) { // metal.cpp:140-144, mirror.cpp:63-67, glass.cpp:245-249
     float roughness = clamp_(eval_slot1(s, m.slot[slot_r], uv), rmin, 1.f);
@@ -990,7 +1021,7 @@ inline void microfacet_alpha(const vmk_scene *s, const vmk_material &m, int slot
 }
 inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const Interaction &it, Lobe &l) {
     l = Lobe{};
-    l.frame = it.shading; // Material::compute_shading_frame without normal map (material.cpp:331-353)
+    l.frame = compute_shading_frame(s, m, it); // Material::compute_shading_frame (material.cpp:331-353)
     switch (m.type) {
         case VMK_MAT_DIFFUSE: { // diffuse.cpp:21-30
             l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
@@ -1065,7 +1096,8 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
         default: break;
     }
 }
-inline void build_principled(const vmk_scene *s, const vmk_material &m, const Interaction &it, LobeSet &out) { // principled_bsdf.cpp:352-461
+inline void build_principled(const vmk_scene *s, const vmk_material &m, const Interaction &it_in, LobeSet &out) { // principled_bsdf.cpp:352-461
+    Interaction it = it_in; it.shading = compute_shading_frame(s, m, it_in); // :353 — every lobe below takes it.shading as its frame
     out.is_set = true; out.n = 0;
     float2 uv = it.uv;
     float3 color = eval_slot_albedo(s, m.slot[VMK_P_COLOR], uv);
@@ -1169,7 +1201,8 @@ inline void build_lobe_set(const vmk_scene *s, const vmk_material &m, const Inte
             const vmk_material &cm = s->materials[c == 0 ? m.child0 : m.child1];
             if (cm.type == VMK_MAT_PRINCIPLED) {
                 LobeSet sub; build_principled(s, cm, it, sub);
-                for (int i = 0; i < sub.n; ++i) { Lobe l = sub.lobes[i]; l.sample_weight *= sw[c]; l.weight *= w[c]; out.lobes[out.n++] = l; }
+                // flatten (lobe.cpp:546-553): parent_weight = the parent's SAMPLING weight, applied to both sub-lobe weights
+                for (int i = 0; i < sub.n; ++i) { Lobe l = sub.lobes[i]; l.sample_weight *= sw[c]; l.weight *= sw[c]; out.lobes[out.n++] = l; }
             } else {
                 Lobe l; build_simple_lobe(s, cm, it, l);
                 l.sample_weight = sw[c]; l.weight = w[c];

@@ -17,6 +17,8 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          ("cbox_lights", "scenes/cbox/cbox_lights.json", 32, 32, 4), ("cbox_sinc", "scenes/cbox/cbox_sinc.json", 32, 32, 4),
          ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
          ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4), ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4), ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4),
+         # Material::compute_shading_frame with "normal" slots, mix / add with a principled_bsdf child (LobeSet::flatten), shape/sphere
+         ("cbox_normal", "scenes/cbox/cbox_normal.json", 32, 32, 4),
          # spectrum/hero: every material family incl. dispersive BK7 glass + measured Cu, textures; diffuse only;
          # media; point + spot lights; config 4 "spectral glass"; classroom with its environment map and textures
          ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),

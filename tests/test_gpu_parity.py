@@ -52,7 +52,8 @@ def test_device_units_rng_math_warps_microfacet(backend):
     assert _bits_equal(backend.test_eval(3, a, 8), oracle_py.test_eval_noscene(3, a, 8))
 
 
-@pytest.mark.parametrize("scene", ["scenes/cbox/cbox_matte.json", "scenes/cbox/cbox_materials.json", "scenes/cbox/cbox_media.json", "scenes/cbox/cbox_sheen.json", "scenes/cbox/cbox_extra.json"])
+@pytest.mark.parametrize("scene", ["scenes/cbox/cbox_matte.json", "scenes/cbox/cbox_materials.json", "scenes/cbox/cbox_media.json", "scenes/cbox/cbox_sheen.json", "scenes/cbox/cbox_extra.json",
+                                   "scenes/cbox/cbox_normal.json"])
 def test_material_camera_and_path_units(backend, scene):
     """Every material type: evaluate + sample on random (wo, wi, uv, rng stream); camera rays; whole-path records."""
     hs, p, osc, _ = _load(backend, scene, 48, 48, mediums=scene.endswith("cbox_media.json"))
@@ -105,6 +106,7 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("cbox_power", "scenes/cbox/cbox_power.json", 32, 32, 4),           # lightsampler/power
     ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4),           # principled_bsdf sheen (LTC) layer
     ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4),           # material/metallic, material/add
+    ("cbox_normal", "scenes/cbox/cbox_normal.json", 32, 32, 4),         # normal-mapped shading frames, mix/add of principled + single lobe, shape/sphere
     # spectrum/hero (§8f-2): the vmk_hero.hip instance of the megakernel, all four <FULL, MEDIA> variants
     ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4),             # every material family, dispersive BK7 glass, measured Cu, texture
     ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4), # single-lobe variant
@@ -321,7 +323,7 @@ def test_hip_albedo_precompute_matches_oracle_and_reference_tables(backend, whic
 
 
 @pytest.mark.parametrize("scene, w, h, kw", [("scenes/cbox/cbox_materials.json", 64, 64, {}), ("scenes/classroom/vision_scene.json", 96, 54, {}), ("scenes/cbox/cbox_sheen.json", 48, 48, {}), ("scenes/cbox/cbox_extra.json", 48, 48, {}),
-                                            ("scenes/cbox/cbox_lights.json", 40, 40, {})])
+                                            ("scenes/cbox/cbox_lights.json", 40, 40, {}), ("scenes/cbox/cbox_normal.json", 48, 48, {})])
 def test_aov_planes_match_oracle(backend, scene, w, h, kw):
     """vmk_render_aov (the reference's G-buffer kernel, frame_buffer.cpp:156-219): shading normal, linear depth, material
     albedo (every lobe class incl. the LUT-based coat / specular albedos of principled_bsdf) and emission, bit for bit."""

@@ -1,7 +1,7 @@
 """ctypes mirror of include/vmk.h and include/vmk_host.h (plain C structs, no torch types)."""
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SLOT_SPD = 0xFFFFFFFD
 SPECTRUM_SRGB, SPECTRUM_HERO = 0, 1
 RGB2SPEC_RES = 64
@@ -18,7 +18,7 @@ class Slot(C.Structure):
 
 
 class Material(C.Structure):
-    _fields_ = [("type", u32), ("flags", u32), ("child0", u32), ("child1", u32), ("slot", Slot * MAX_SLOTS)]
+    _fields_ = [("type", u32), ("flags", u32), ("child0", u32), ("child1", u32), ("slot", Slot * MAX_SLOTS), ("normal", Slot)]
 
 
 class Light(C.Structure):

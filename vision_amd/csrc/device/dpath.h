@@ -792,6 +792,38 @@ VD V3 sample_wi_local_call(uint32_t lds, V3 wo, Sampler &sampler, bool *valid) {
     return r.wi;
 }
 
+// Material::compute_shading_frame (material.cpp:331-353): the frame every lobe of the material evaluates in.  Without a "normal"
+// slot it is the interaction's; with one, the rotation that takes (0,0,1) to the slot's value (used as it comes) is applied to
+// the world shading normal, the result is clamped against the geometric normal (detail::clamp_ns :305-310) and the tangents are
+// re-derived (PartialDerivative::update(n, s), interaction.h:106-112).  Quaternion::from_axis_angle / to_float3x3 are ocarina's:
+// restated as Rodrigues' rotation about normalize(axis), like the oracle (parity unpinned).
+VD Frame compute_shading_frame(const DScene &S, const vmk_material *m, const Interaction &it, DCounters &cnt) {
+    Frame ret = it.shading;
+    if (!(m->flags & VMK_MATF_HAS_NORMAL)) return ret;
+    V3 normal = eval_slot3(S, m->normal, it.uv, cnt);
+    V3 n = mk3(0.f, 0.f, 1.f);
+    V3 axis = cross(n, normal);
+    float theta = acos_(clamp_(dot(n, normal), -1.f, 1.f));
+    V3 world_normal = ret.z;
+    float len = length(axis);
+    if (len > 0.f) {
+        V3 k = axis / len;
+        float st, ct; sincos_(theta, &st, &ct);
+        world_normal = ret.z * ct + cross(k, ret.z) * st + k * (dot(k, ret.z) * (1.f - ct));
+    }
+    world_normal = normalize(world_normal);
+    { // clamp_ns(ns, ng, w = wo)
+        V3 w_refl = reflect(it.wo, world_normal);
+        V3 w_refl_clip = same_hemisphere(it.wo, w_refl, it.ng) ? w_refl : normalize(w_refl - it.ng * dot(w_refl, it.ng));
+        world_normal = normalize(w_refl_clip + it.wo);
+    }
+    world_normal = normalize(face_forward(world_normal, it.shading.z));
+    V3 ss = normalize(ret.x - world_normal * dot(world_normal, ret.x));
+    V3 tt = normalize(cross(world_normal, ss));
+    ret.z = world_normal; ret.x = ss; ret.y = tt;
+    return ret;
+}
+
 VD void microfacet_alpha(const DScene &S, const vmk_material *m, int slot_r, int slot_a, V2 uv, float rmin, float *ax, float *ay, DCounters &cnt) {
     float roughness = clamp_(eval_slot1(S, m->slot[slot_r], uv, cnt), rmin, 1.f);
     float anisotropic = clamp_(eval_slot1(S, m->slot[slot_a], uv, cnt), -0.9f, 0.9f);
@@ -903,6 +935,9 @@ struct MatCtx {
     Lobe single;  // simple materials: the lobe itself
     uint32_t lobe_lds; // this lane's slot in the wave's idle traversal scratch (byte offset in LDS), set by the caller of mat_prepare
     float mixw[2], mixsw[2]; // mix / add: lobe weights and sampling weights of the two children
+    const vmk_material *pm;  // the principled_bsdf material the principled fields below describe: m itself, or the ONE principled child
+                             // of a mix / add whose lobes LobeSet::flatten (lobe.cpp:534-562) merges into the parent's list
+    int pchild;              // mix / add: which child (0 / 1) is the principled one, -1: both are single-lobe
     // principled
     int first;    // 0 with sheen, 1 without
     V3 color, spec_tint, kr_sheen, kr_coat, kr_metal, kr_spec, kr_diff;
@@ -921,20 +956,23 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
         build_simple_lobe(S, m, it, mc.single, cnt SWL_A);
         return;
     }
-    if (m->type == VMK_MAT_MIX) { // mix.cpp:66-71 + LobeSet::create_mix (lobe.cpp:495-508)
-        float frac = eval_slot1(S, m->slot[0], it.uv, cnt);
-        mc.mixw[0] = 1.f - frac; mc.mixw[1] = frac;
-        mc.mixsw[0] = 1.f - frac; mc.mixsw[1] = frac;
+    mc.pm = m; mc.pchild = -1;
+    if (m->type == VMK_MAT_MIX || m->type == VMK_MAT_ADD) {
+        if (m->type == VMK_MAT_MIX) { // mix.cpp:66-71 + LobeSet::create_mix (lobe.cpp:495-508)
+            float frac = eval_slot1(S, m->slot[0], it.uv, cnt);
+            mc.mixw[0] = 1.f - frac; mc.mixw[1] = frac;
+            mc.mixsw[0] = 1.f - frac; mc.mixsw[1] = frac;
+        } else { // add.cpp:57-60 + LobeSet::create_add (lobe.cpp:510-522): weights {1, 1}, sampling weights normalised
+            mc.mixw[0] = 1.f; mc.mixw[1] = 1.f;
+            mc.mixsw[0] = 1.f / (1.f + 1.f); mc.mixsw[1] = 1.f / (1.f + 1.f);
+        }
         mc.n = 2; mc.is_set = true;
-        return;
-    }
-    if (m->type == VMK_MAT_ADD) { // add.cpp:57-60 + LobeSet::create_add (lobe.cpp:510-522): weights {1, 1}, sampling weights normalised
-        mc.mixw[0] = 1.f; mc.mixw[1] = 1.f;
-        mc.mixsw[0] = 1.f / (1.f + 1.f); mc.mixsw[1] = 1.f / (1.f + 1.f);
-        mc.n = 2; mc.is_set = true;
-        return;
-    }
-    if (m->type != VMK_MAT_PRINCIPLED) {
+        const vmk_material *c0 = S.materials + m->child0, *c1 = S.materials + m->child1;
+        if (c0->type != VMK_MAT_PRINCIPLED && c1->type != VMK_MAT_PRINCIPLED) return;
+        mc.pchild = c0->type == VMK_MAT_PRINCIPLED ? 0 : 1; // (the host admits one principled child at most)
+        mc.pm = mc.pchild == 0 ? c0 : c1;
+        m = mc.pm; // fall through: prepare the principled child; its lobes are flattened into this set by mat_lobe
+    } else if (m->type != VMK_MAT_PRINCIPLED) {
         mc.n = 1; mc.is_set = false;
         build_simple_lobe(S, m, it, mc.single, cnt SWL_A);
         return;
@@ -1020,18 +1058,25 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
 #pragma unroll
     for (int i = 0; i < 6; ++i) if (i >= mc.first) mc.sw[i] = mc.sw[i] / weight_sum;
     mc.n = 6 - mc.first;
+    if (mc.pchild >= 0) mc.n += 1; // + the single-lobe sibling
 }
 // expand lobe `i` (0-based within the material's lobe list)
 template<bool FULL>
 VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i, Lobe &l, DCounters &cnt SWL_P) {
     if constexpr (!FULL) { l = mc.single; return; }
     const vmk_material *m = mc.m;
+    float parent = 1.f; // LobeSet::flatten: a principled child's sub-lobes take the parent's SAMPLING weight on both of their weights
     if (m->type == VMK_MAT_MIX || m->type == VMK_MAT_ADD) {
-        build_simple_lobe(S, S.materials + (i == 0 ? m->child0 : m->child1), it, l, cnt SWL_A);
-        l.weight = i == 0 ? mc.mixw[0] : mc.mixw[1]; l.sample_weight = i == 0 ? mc.mixsw[0] : mc.mixsw[1];
-        return;
-    }
-    if (m->type != VMK_MAT_PRINCIPLED) { l = mc.single; return; }
+        const int np = mc.pchild >= 0 ? mc.n - 1 : 0; // lobes of the principled child in the flat list
+        const int child = mc.pchild < 0 ? i : (mc.pchild == 0 ? (i < np ? 0 : 1) : (i == 0 ? 0 : 1));
+        if (child != mc.pchild) {
+            build_simple_lobe(S, S.materials + (child == 0 ? m->child0 : m->child1), it, l, cnt SWL_A);
+            l.weight = child == 0 ? mc.mixw[0] : mc.mixw[1]; l.sample_weight = child == 0 ? mc.mixsw[0] : mc.mixsw[1];
+            return;
+        }
+        parent = child == 0 ? mc.mixsw[0] : mc.mixsw[1];
+        i = mc.pchild == 0 ? i : i - 1;
+    } else if (m->type != VMK_MAT_PRINCIPLED) { l = mc.single; return; }
     lobe_defaults(l);
     int k = i + mc.first;
     l.sample_weight = k == 0 ? mc.sw[0] : k == 1 ? mc.sw[1] : k == 2 ? mc.sw[2] : k == 3 ? mc.sw[3] : k == 4 ? mc.sw[4] : mc.sw[5];
@@ -1043,15 +1088,16 @@ VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i
         case 4: l.kind = LB_MICROFACET; l.ax = mc.ax; l.ay = mc.ay; l.fr.kind = FR_SCHLICK; l.fr.a = mc.f0_spec; l.fr.eta = mc.ior; l.kr = mc.kr_spec; break;
         default: l.kind = LB_LAMBERT; l.kr = mc.kr_diff; break;
     }
+    if (mc.pchild >= 0) { l.weight *= parent; l.sample_weight *= parent; }
 }
 // MaterialEvaluator::albedo (material.cpp:91-98) = LobeSet::albedo (lobe.cpp:564-570) over the per-class Lobe::albedo
 // (bxdf.h:91,153; substrate.cpp:22; lobe.cpp:208-210,308-313; CoatLobe / SpecularLobe principled_bsdf.cpp:154-160,198-205);
 // used by the AOV pass only (frame_buffer.cpp:192-196), always instantiated with FULL = true.
 #if !VMK_HERO
-VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, const Lobe &l, float cos_theta) {
+VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, bool principled_lobe, const Lobe &l, float cos_theta) {
     switch (l.kind) {
         case LB_MICROFACET: {
-            if (mc.is_set && mc.m->type == VMK_MAT_PRINCIPLED && (k == 1 || k == 4)) {
+            if (mc.is_set && principled_lobe && (k == 1 || k == 4)) {
                 float x = sqrt_(sqrt_(l.ax * l.ay));
                 if (k == 1) { float sv; sample_lut3d<1>(S.lut_coat, mk3(x, cos_theta, inverse_lerp(mc.cc_ior, 1.003f, 4.f)), &sv); return sv * l.kr; }
                 float z = sqrt_(abs_((mc.ior - 1.0f) / (mc.ior + 1.0f)));
@@ -1068,11 +1114,13 @@ VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, const Lobe &l, float
 VD V3 mat_albedo(const DScene &S, const MatCtx &mc, const Interaction &it, DCounters &cnt) {
     float cos_theta = dot(it.shading.z, it.wo);
     Lobe l;
-    if (!mc.is_set) { mat_lobe<true>(S, mc, it, 0, l, cnt); return lobe_albedo(S, mc, 0, l, cos_theta); }
+    if (!mc.is_set) { mat_lobe<true>(S, mc, it, 0, l, cnt); return lobe_albedo(S, mc, 0, false, l, cos_theta); }
     V3 sum = mk3(0.f);
     for (int i = 0; i < mc.n; ++i) {
         mat_lobe<true>(S, mc, it, i, l, cnt);
-        sum += lobe_albedo(S, mc, i + (mc.m->type == VMK_MAT_PRINCIPLED ? mc.first : 0), l, cos_theta) * l.weight;
+        bool pl = mc.m->type == VMK_MAT_PRINCIPLED; int ip = i;
+        if (mc.pchild >= 0) { const int np = mc.n - 1; pl = mc.pchild == 0 ? i < np : i > 0; ip = mc.pchild == 0 ? i : i - 1; }
+        sum += lobe_albedo(S, mc, pl ? ip + mc.first : 0, pl, l, cos_theta) * l.weight;
     }
     return sum;
 }
@@ -1117,8 +1165,14 @@ VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sa
         float sum_weights = 0.f;
         for (int i = 0; i < mc.n; ++i) {
             float sw;
-            if (mc.m->type == VMK_MAT_MIX || mc.m->type == VMK_MAT_ADD) sw = i == 0 ? mc.mixsw[0] : mc.mixsw[1];
-            else { int k = i + mc.first; sw = k == 0 ? mc.sw[0] : k == 1 ? mc.sw[1] : k == 2 ? mc.sw[2] : k == 3 ? mc.sw[3] : k == 4 ? mc.sw[4] : mc.sw[5]; }
+            int ip = i; float parent = 1.f; bool principled = mc.m->type == VMK_MAT_PRINCIPLED;
+            if (mc.m->type == VMK_MAT_MIX || mc.m->type == VMK_MAT_ADD) {
+                const int np = mc.pchild >= 0 ? mc.n - 1 : 0;
+                const int child = mc.pchild < 0 ? i : (mc.pchild == 0 ? (i < np ? 0 : 1) : (i == 0 ? 0 : 1));
+                sw = child == 0 ? mc.mixsw[0] : mc.mixsw[1];
+                if (child == mc.pchild) { principled = true; parent = sw; ip = mc.pchild == 0 ? i : i - 1; }
+            }
+            if (principled) { int k = ip + mc.first; sw = (k == 0 ? mc.sw[0] : k == 1 ? mc.sw[1] : k == 2 ? mc.sw[2] : k == 3 ? mc.sw[3] : k == 4 ? mc.sw[4] : mc.sw[5]) * parent; }
             strategy = uc > sum_weights ? i : strategy;
             sum_weights += sw;
         }

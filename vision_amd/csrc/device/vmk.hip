@@ -332,6 +332,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
             it.uv = {a[10], a[11]};
             it.mat_id = mat_id; it.light_id = VMK_INVALID; it.prim_id = 0; it.prim_area = 1.f;
             V3 wi = normalize(mk3(a[7], a[8], a[9]));
+            it.shading = compute_shading_frame(S, S.materials + mat_id, it, cnt);
             MatCtx mc; mc.lobe_lds = lobe_lds_slot(s_ws); mat_prepare<true>(S, S.materials + mat_id, it, mc, cnt);
             Sampler smp; smp.start(f2u(a[1]), f2u(a[2]), f2u(a[3]), 1);
             ScatterEval se; BSDFSample bs;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
                 motion = {p_film.x - rc.x, p_film.y - rc.y};
             }
             if (it.mat_id != VMK_INVALID) {
-                MatCtx mc;
+                MatCtx mc; // (the albedo of a lobe does not depend on its shading frame: no compute_shading_frame here)
                 mat_prepare<true>(S, S.materials + it.mat_id, it, mc, cnt);
                 albedo = mat_albedo(S, mc, it, cnt);
             }
@@ -735,6 +736,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     for (uint32_t i = 0; i < sc->n_materials; ++i) {
         const vmk_material &m = sc->materials[i];
         if (m.type > VMK_MAT_PLASTIC) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
+        if ((m.flags & VMK_MATF_HAS_NORMAL) && (m.normal.tex == VMK_SLOT_SPD || !slot_ok(m.normal) || m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD)) { ctx->error = "vmk_upload_scene: bad normal slot"; return VMK_ERR_ARG; }
         for (int k = 0; k < VMK_MAX_SLOTS; ++k) {
             const vmk_slot &s = m.slot[k];
             const bool spd_allowed = (m.type == VMK_MAT_METAL && k < 2) || (m.type == VMK_MAT_GLASS && k == 1);
@@ -744,7 +746,9 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
         if (m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD) {
             if (m.child0 >= sc->n_materials || m.child1 >= sc->n_materials) { ctx->error = "vmk_upload_scene: mix child out of range"; return VMK_ERR_ARG; }
             uint32_t t0 = sc->materials[m.child0].type, t1 = sc->materials[m.child1].type;
-            if (!VMK_MAT_IS_SINGLE_LOBE(t0) || !VMK_MAT_IS_SINGLE_LOBE(t1)) { ctx->error = "vmk_upload_scene: mix / add children must be single-lobe materials"; return VMK_ERR_UNSUPPORTED; }
+            const bool ok0 = VMK_MAT_IS_SINGLE_LOBE(t0) || t0 == VMK_MAT_PRINCIPLED, ok1 = VMK_MAT_IS_SINGLE_LOBE(t1) || t1 == VMK_MAT_PRINCIPLED;
+            if (!ok0 || !ok1 || (t0 == VMK_MAT_PRINCIPLED && t1 == VMK_MAT_PRINCIPLED)) { ctx->error = "vmk_upload_scene: mix / add children must be single-lobe materials, or one principled_bsdf next to a single-lobe material"; return VMK_ERR_UNSUPPORTED; }
+            if ((sc->materials[m.child0].flags | sc->materials[m.child1].flags) & VMK_MATF_HAS_NORMAL) { ctx->error = "vmk_upload_scene: normal maps on the children of mix / add are not supported (per-lobe shading frames)"; return VMK_ERR_UNSUPPORTED; }
         }
         if (m.type == VMK_MAT_PRINCIPLED && !sc->luts.sheen_approx && (m.slot[VMK_P_SHEEN_WEIGHT].tex != VMK_INVALID || m.slot[VMK_P_SHEEN_WEIGHT].v[0] != 0.f)) { ctx->error = "vmk_upload_scene: sheen needs the LTC tables"; return VMK_ERR_UNSUPPORTED; }
     }

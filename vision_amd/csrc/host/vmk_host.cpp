@@ -444,7 +444,12 @@ struct HostScene {
         vmk_material m{};
         for (auto &s : m.slot) s.tex = VMK_INVALID;
         m.child0 = m.child1 = VMK_INVALID;
-        if (p.contains("normal")) fail("material '" + name + "': normal maps are outside the hot-path scope");
+        m.normal.tex = VMK_INVALID;
+        if (p.contains("normal")) { // Material::initialize_slots material.cpp:312-316: VS_INIT_SLOT_NO_DEFAULT(normal, Number)
+            if (type == "mix" || type == "add") fail("material '" + name + "': a normal slot on mix / add has no effect in the reference (only its children build lobes) and is not accepted");
+            m.normal = parse_slot(p, "normal", 3, {0.f, 0.f, 1.f});
+            m.flags |= VMK_MATF_HAS_NORMAL;
+        }
         bool remap = p["remapping_roughness"].as_bool(true);
         if (remap) m.flags |= VMK_MATF_REMAP_ROUGHNESS;
         if (type == "diffuse") { // diffuse.cpp:41-48
@@ -517,7 +522,12 @@ struct HostScene {
         } else if (type == "mix" || type == "add") { // mix.cpp:27-41, add.cpp:17-27
             m.type = type == "mix" ? VMK_MAT_MIX : VMK_MAT_ADD;
             uint32_t c0 = add_material(p["mat0"]), c1 = add_material(p["mat1"]);
-            if (!VMK_MAT_IS_SINGLE_LOBE(materials[c0].type) || !VMK_MAT_IS_SINGLE_LOBE(materials[c1].type)) fail("material '" + name + "': " + type + " of lobe-set materials (principled_bsdf / mix / add) is outside the hot-path scope");
+            // LobeSet::flatten (lobe.cpp:534-562) merges a lobe-set child's lobes into the parent's list: one principled_bsdf child next to a
+            // single-lobe child is carried (the reference's own cbox/cbox.json); two lobe-set children, or nested mix / add, are not
+            const uint32_t t0 = materials[c0].type, t1 = materials[c1].type;
+            const bool ok0 = VMK_MAT_IS_SINGLE_LOBE(t0) || t0 == VMK_MAT_PRINCIPLED, ok1 = VMK_MAT_IS_SINGLE_LOBE(t1) || t1 == VMK_MAT_PRINCIPLED;
+            if (!ok0 || !ok1 || (t0 == VMK_MAT_PRINCIPLED && t1 == VMK_MAT_PRINCIPLED)) fail("material '" + name + "': " + type + " of two lobe-set materials (principled_bsdf / mix / add) is outside the hot-path scope (one principled_bsdf child next to a single-lobe child is supported)");
+            if ((materials[c0].flags | materials[c1].flags) & VMK_MATF_HAS_NORMAL) fail("material '" + name + "': normal maps on the children of " + type + " are outside the hot-path scope");
             m.child0 = c0; m.child1 = c1;
             if (type == "mix") m.slot[0] = parse_slot(p, "frac", 1, {0.5f});
         } else fail("material type '" + type + "' (" + name + ") is outside the hot-path scope (SURVEY.md §2)");
@@ -539,6 +549,40 @@ struct HostScene {
         float ng[3] = {dp02[1] * dp12[2] - dp02[2] * dp12[1], dp02[2] * dp12[0] - dp02[0] * dp12[2], dp02[0] * dp12[1] - dp02[1] * dp12[0]};
         for (int i = 0; i < 4; ++i) { Vtx v{}; std::memcpy(v.p, P[i], 12); std::memcpy(v.n, ng, 12); std::memcpy(v.uv, UV[i], 8); m.v.push_back(v); }
         m.idx = {0, 1, 2, 2, 1, 3};
+        return m;
+    }
+    static Mesh make_sphere(const Json &p) { // sphere.cpp:20-88: latitude / longitude tessellation, same vertex and triangle order
+        Mesh m;
+        const float radius = p["radius"].as_float(1.f);
+        const uint32_t theta_div = std::max(2u, p["sub_div"].as_uint(60u)), phi_div = 2 * theta_div;
+        const float Pi = 3.14159265358979323846f, TwoPi = 6.28318530717958647692f;
+        auto push = [&](float x, float y, float z, float u, float v) {
+            Vtx vt{}; vt.p[0] = x; vt.p[1] = y; vt.p[2] = z; vt.uv[0] = u; vt.uv[1] = v;
+            float l = std::sqrt(x * x + y * y + z * z);
+            vt.n[0] = x / l; vt.n[1] = y / l; vt.n[2] = z / l;
+            m.v.push_back(vt);
+        };
+        push(0.f, radius, 0.f, 0.f, 0.f);
+        for (uint32_t i = 1; i < theta_div; ++i) {
+            float v = float(i) / theta_div, theta = Pi * v, y = radius * std::cos(theta), r = radius * std::sin(theta);
+            push(r, y, 0.f, 0.f, v);
+            for (uint32_t j = 1; j < phi_div; ++j) {
+                float u = float(j) / phi_div, phi = u * TwoPi;
+                push(std::cos(phi) * r, y, std::sin(phi) * r, u, v);
+            }
+        }
+        push(0.f, -radius, 0.f, 0.f, 1.f);
+        auto tri = [&](uint32_t a, uint32_t b, uint32_t c) { m.idx.push_back(a); m.idx.push_back(b); m.idx.push_back(c); };
+        for (uint32_t i = 0; i < phi_div; ++i) tri(0, (i + 1) % phi_div + 1, i + 1);
+        for (uint32_t i = 0; i + 2 < theta_div; ++i) {
+            uint32_t vs = 1 + i * phi_div;
+            for (uint32_t j = 0; j < phi_div; ++j, ++vs) {
+                if (j != phi_div - 1) { tri(vs, vs + 1, vs + phi_div); tri(vs + 1, vs + phi_div + 1, vs + phi_div); }
+                else { tri(vs, vs + 1 - phi_div, vs + phi_div); tri(vs + 1 - phi_div, vs + 1, vs + phi_div); }
+            }
+        }
+        const uint32_t ve = (uint32_t) m.v.size() - 1;
+        for (uint32_t i = 0; i < phi_div; ++i) tri(ve, ve - ((1 + i) % phi_div + 1), ve - (i + 1));
         return m;
     }
     static Mesh make_cube(const Json &p) { // cube.cpp:21-72
@@ -786,6 +830,7 @@ struct HostScene {
             Mesh mesh;
             if (type == "quad") mesh = make_quad(p);
             else if (type == "cube") mesh = make_cube(p);
+            else if (type == "sphere") mesh = make_sphere(p);
             else if (type == "model") {
                 std::string fn = p["fn"].as_string();
                 if (p["swap_handed"].as_bool(false) || p["subdiv_level"].as_uint(0)) fail("shape/model swap_handed/subdiv_level are outside the hot-path scope");
@@ -795,7 +840,7 @@ struct HostScene {
                     continue;
                 }
                 mesh = list_only ? Mesh{} : load_obj(join_path(scene_dir, fn), p["flip_uv"].as_bool(true), p["smooth"].as_bool(false));
-            } else fail("shape/" + type + " is outside the hot-path scope (quad/cube/model)");
+            } else fail("shape/" + type + " is outside the hot-path scope (quad/cube/sphere/model)");
             describe("shape", type, sd["name"].as_string());
             std::string mat_name = p["material"].as_string();
             uint32_t mat_id = VMK_INVALID;
