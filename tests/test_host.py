@@ -105,7 +105,7 @@ def test_json_comments_and_defaults(built, tmp_path):
     (lambda s: s["spectrum"].update(type="rgb"), "spectrum/rgb"),
     (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "projector", "param": {}}), "light/projector"),
     (lambda s: s["camera"]["param"].update(filter={"type": "blackman", "param": {"radius": 1}}), "filter/blackman"),
-    (lambda s: s["shapes"].append({"type": "sphere", "name": "s", "param": {}}), "shape/sphere"),
+    (lambda s: s["shapes"].append({"type": "torus", "name": "s", "param": {}}), "shape/torus"),
     (lambda s: s["shapes"][-1]["param"].pop("emission"), "no light"),
 ])
 def test_out_of_scope_features_fail_loudly(built, tmp_path, mutate, needle):
@@ -261,3 +261,28 @@ def test_malformed_assets_fail_instead_of_hanging(built, tmp_path):
         path = os.path.join(tmp_path, fn + ".json"); json.dump(sc3, open(path, "w"))
         with pytest.raises(HostError, match="nor decodable"):
             HostScene(path, width=16, height=16, procedural_env=False)
+
+
+def test_sphere_tessellation_and_normal_slot(built, tmp_path):
+    """shape/sphere (sphere.cpp:20-88): 2 x sub_div^2 x 2 - ... triangles in the reference's vertex / triangle order, unit normals;
+    a material's "normal" slot sets VMK_MATF_HAS_NORMAL; mix / add accept ONE principled_bsdf child (LobeSet::flatten)."""
+    sc = _cbox()
+    ident = {"type": "matrix4x4", "param": {"matrix4x4": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 1, 0, 1]]}}
+    sc["shapes"].append({"type": "sphere", "name": "ball", "param": {"radius": 0.25, "sub_div": 8, "material": sc["materials"][0]["name"], "transform": ident}})
+    sc["materials"][0]["param"]["normal"] = [0.1, 0.2, 0.97]
+    hs = HostScene(_write(tmp_path, "sph.json", sc), width=16, height=16)
+    theta, phi = 8, 16
+    assert hs.scene.n_tris == 36 + phi * 2 + (theta - 2) * phi * 2
+    tp = np.ctypeslib.as_array(hs.scene.tri_pos, shape=(hs.scene.n_tris,))
+    ball = tp[tp["inst"] == hs.scene.n_instances - 1]
+    pts = np.concatenate([np.array(ball["p0"]), np.array(ball["p1"]), np.array(ball["p2"])])
+    assert np.allclose(np.linalg.norm(pts - np.array([0, 1, 0]), axis=1), 0.25, atol=1e-6)
+    m0 = hs.scene.materials[0]
+    assert m0.flags & 8 and np.allclose(list(m0.normal.v), [0.1, 0.2, 0.97])
+    # mix with one principled child is in scope, with two it is not
+    pr = {"type": "principled_bsdf", "name": "p", "param": {"color": [0.5, 0.5, 0.5]}}
+    sc["materials"].append({"type": "mix", "name": "mx", "param": {"mat0": pr, "mat1": {"type": "diffuse", "name": "d", "param": {}}, "frac": 0.4}})
+    HostScene(_write(tmp_path, "mx.json", sc), width=16, height=16)
+    sc["materials"][-1]["param"]["mat1"] = dict(pr, name="p2")
+    with pytest.raises(HostError, match="two lobe-set"):
+        HostScene(_write(tmp_path, "mx2.json", sc), width=16, height=16)

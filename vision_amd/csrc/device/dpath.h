@@ -797,31 +797,50 @@ VD V3 sample_wi_local_call(uint32_t lds, V3 wo, Sampler &sampler, bool *valid) {
 // the world shading normal, the result is clamped against the geometric normal (detail::clamp_ns :305-310) and the tangents are
 // re-derived (PartialDerivative::update(n, s), interaction.h:106-112).  Quaternion::from_axis_angle / to_float3x3 are ocarina's:
 // restated as Rodrigues' rotation about normalize(axis), like the oracle (parity unpinned).
-VD Frame compute_shading_frame(const DScene &S, const vmk_material *m, const Interaction &it, DCounters &cnt) {
-    Frame ret = it.shading;
-    if (!(m->flags & VMK_MATF_HAS_NORMAL)) return ret;
-    V3 normal = eval_slot3(S, m->normal, it.uv, cnt);
+// Out of line and by value: inlined into path_bounce its acos / sincos / normalisations cost the megakernel 38 % on scenes that
+// have no normal map at all (register pressure around the shading code), as a call they cost those scenes one flag test.
+struct FrameRet { V3 x, y, z; };
+__device__ __noinline__ FrameRet normal_mapped_frame_ool(const vmk_texture *textures, const uint8_t *tex_data, const float *srgb_lut,
+                                                         float s0, float s1, float s2, uint32_t stex, float uvx, float uvy,
+                                                         float xx, float xy, float xz, float zx, float zy, float zz,
+                                                         float gx, float gy, float gz, float wx, float wy, float wz) {
+    V3 normal = {s0, s1, s2};
+    if (stex != VMK_INVALID) { // ShaderNodeSlot::evaluate (eval_slot3) against the three texture tables
+        float4 t = sample_image_ool(textures, tex_data, srgb_lut, stex & 0xffffu, uvx, uvy);
+        float c[4] = {t.x * s0, t.y * s0, t.z * s0, t.w * s0};
+        uint32_t sw = stex >> 16;
+        auto pick = [&](uint32_t k) { return k == 0 ? c[0] : (k == 1 ? c[1] : (k == 2 ? c[2] : c[3])); };
+        normal = {pick(sw & 3u), pick((sw >> 2) & 3u), pick((sw >> 4) & 3u)};
+    }
+    const V3 sx = {xx, xy, xz}, sz = {zx, zy, zz}, ng = {gx, gy, gz}, wo = {wx, wy, wz};
     V3 n = mk3(0.f, 0.f, 1.f);
     V3 axis = cross(n, normal);
     float theta = acos_(clamp_(dot(n, normal), -1.f, 1.f));
-    V3 world_normal = ret.z;
+    V3 world_normal = sz;
     float len = length(axis);
     if (len > 0.f) {
         V3 k = axis / len;
         float st, ct; sincos_(theta, &st, &ct);
-        world_normal = ret.z * ct + cross(k, ret.z) * st + k * (dot(k, ret.z) * (1.f - ct));
+        world_normal = sz * ct + cross(k, sz) * st + k * (dot(k, sz) * (1.f - ct));
     }
     world_normal = normalize(world_normal);
     { // clamp_ns(ns, ng, w = wo)
-        V3 w_refl = reflect(it.wo, world_normal);
-        V3 w_refl_clip = same_hemisphere(it.wo, w_refl, it.ng) ? w_refl : normalize(w_refl - it.ng * dot(w_refl, it.ng));
-        world_normal = normalize(w_refl_clip + it.wo);
+        V3 w_refl = reflect(wo, world_normal);
+        V3 w_refl_clip = same_hemisphere(wo, w_refl, ng) ? w_refl : normalize(w_refl - ng * dot(w_refl, ng));
+        world_normal = normalize(w_refl_clip + wo);
     }
-    world_normal = normalize(face_forward(world_normal, it.shading.z));
-    V3 ss = normalize(ret.x - world_normal * dot(world_normal, ret.x));
+    world_normal = normalize(face_forward(world_normal, sz));
+    V3 ss = normalize(sx - world_normal * dot(world_normal, sx));
     V3 tt = normalize(cross(world_normal, ss));
-    ret.z = world_normal; ret.x = ss; ret.y = tt;
-    return ret;
+    return FrameRet{ss, tt, world_normal};
+}
+VD Frame compute_shading_frame(const DScene &S, const vmk_material *m, const Interaction &it, DCounters &cnt) {
+    if (!(m->flags & VMK_MATF_HAS_NORMAL)) return it.shading;
+    if (m->normal.tex != VMK_INVALID) cnt.tex++;
+    FrameRet r = normal_mapped_frame_ool(S.textures, S.tex_data, S.srgb_lut, m->normal.v[0], m->normal.v[1], m->normal.v[2], m->normal.tex, it.uv.x, it.uv.y,
+                                         it.shading.x.x, it.shading.x.y, it.shading.x.z, it.shading.z.x, it.shading.z.y, it.shading.z.z,
+                                         it.ng.x, it.ng.y, it.ng.z, it.wo.x, it.wo.y, it.wo.z);
+    return Frame{r.x, r.y, r.z};
 }
 
 VD void microfacet_alpha(const DScene &S, const vmk_material *m, int slot_r, int slot_a, V2 uv, float rmin, float *ax, float *ay, DCounters &cnt) {

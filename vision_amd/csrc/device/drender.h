@@ -176,7 +176,9 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
         // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
         MatCtx mc;
         mc.lobe_lds = lobe_lds_slot(ws);
-        it.shading = compute_shading_frame(S, S.materials + it.mat_id, it, cnt); // (identity without a "normal" slot)
+        // (scenes with a "normal" slot anywhere select the FULL variants: the single-lobe kernels carry none of it — even as an
+        // out-of-line call behind a flag test it cost the headline kernel 11 %)
+        if constexpr (FULL) it.shading = compute_shading_frame(S, S.materials + it.mat_id, it, cnt);
         mat_prepare<FULL>(S, S.materials + it.mat_id, it, mc, cnt SWL_A);
 #if VMK_HERO
         // SampledWavelengths::check_dispersive (spectrum.cpp:32-39, integrator.cpp:264): a dispersive lobe keeps the hero wavelength only

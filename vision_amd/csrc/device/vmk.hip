@@ -779,7 +779,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     if (!sc->luts.pure_reflection || !sc->luts.dielectric || !sc->luts.dielectric_inv || !sc->luts.specular || !sc->luts.coat) { ctx->error = "vmk_upload_scene: albedo tables missing"; return VMK_ERR_ARG; }
 
     ctx->full_materials = false;
-    for (uint32_t i = 0; i < sc->n_materials; ++i) if (!VMK_MAT_IS_SINGLE_LOBE(sc->materials[i].type)) ctx->full_materials = true;
+    for (uint32_t i = 0; i < sc->n_materials; ++i) if (!VMK_MAT_IS_SINGLE_LOBE(sc->materials[i].type) || (sc->materials[i].flags & VMK_MATF_HAS_NORMAL)) ctx->full_materials = true;
     if (const char *v = getenv("VMK_FORCE_FULL")) if (v[0] == '1') ctx->full_materials = true;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
