@@ -442,26 +442,69 @@ def test_render_edge_cases(backend, w, h, max_depth, min_depth, tiles):
 
 def test_glass_of_water_agrees_with_the_reference_render(backend):
     """Image-level pin against the reference's OWN output: Vision ships its 1024-spp render of glass-of-water
-    (tests/golden/glass_of_water_ref_blocks.npy = 16x16 block means of that PNG, tools/make_golden_refimage.py).  Away from
-    the glass (the poured-water mesh is missing from the checkout) this backend's render agrees with it to ~2/255 per block
-    after the plain exposure + sRGB encoding that picture turns out to carry, and per-channel energy agrees within 15 %."""
+    (tests/golden/glass_of_water_ref_blocks.npy = 16x16 block means of that PNG, tools/make_golden_refimage.py).  The poured-water
+    mesh (models/Mesh000.obj: the stream, the water in the glass, the splashes) is missing from the checkout, so the blocks it
+    covers are excluded — and ONLY those.  Everything else is compared and reported by region, under the plain exposure + sRGB
+    encoding that picture carries: (a) backdrop + far table, (b) the rough-conductor table around the objects (metal, GGX),
+    (c) the three ice cubes (rough dielectric: refraction, internal reflection, max depth 32), (d) the strip under the glass, which
+    mirrors the missing water and is only held loosely."""
     hs, p, osc, _ = _load(backend, "scenes/glass-of-water/vision_scene.json", 1280, 720)
     backend.reset_accum()
-    backend.render_batch(0, 128)
+    backend.render_batch(0, 256)
     lin = backend.download_accum()[..., :3].astype(np.float64)
     ref = np.load(os.path.join(ROOT, "tests", "golden", "glass_of_water_ref_blocks.npy")).astype(np.float64)
     B = 16
     blocks = lambda img: img[:720 // B * B, :1280 // B * B].reshape(720 // B, B, 1280 // B, B, 3).mean((1, 3))
     srgb = lambda x: np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(np.maximum(x, 1e-12), 1 / 2.4) - 0.055)
     inv_srgb = lambda y: np.where(y <= 0.04045, y / 12.92, np.power((y + 0.055) / 1.055, 2.4))
-    mask = np.ones(ref.shape[:2], bool)
-    mask[:, 24:58] = False                 # glass, water stream
-    mask[28:, 6:70] = False                # ice cubes, puddles, reflections of the stream on the table
+    missing = np.zeros(ref.shape[:2], bool)
+    missing[0:39, 24:54] = True            # the stream, the glass with the water in it, the splashes around its rim
+    region = {"backdrop": np.zeros_like(missing), "table_metal": np.zeros_like(missing), "ice_cubes": np.zeros_like(missing), "under_glass": np.zeros_like(missing)}
+    region["ice_cubes"][33:42, 15:27] = True; region["ice_cubes"][29:38, 54:65] = True
+    region["under_glass"][39:45, 24:54] = True
+    region["table_metal"][31:45, :] = True
+    region["backdrop"][0:31, :] = True
+    for k in ("table_metal", "backdrop"):
+        region[k] &= ~(missing | region["ice_cubes"] | region["under_glass"])
     mine = blocks(srgb(1.0 - np.exp(-lin)))
-    d = (mine - ref)[mask]
-    assert np.abs(d).mean() < 0.015, float(np.abs(d).mean())          # measured 0.0064
-    ratio = blocks(lin)[mask].sum(0) / inv_srgb(ref)[mask].sum(0)      # measured (0.95, 1.09, 1.09)
-    assert (ratio > 0.85).all() and (ratio < 1.15).all(), ratio
+    lin_b, ref_lin = blocks(lin), inv_srgb(ref)
+    limits = {"backdrop": (0.02, 0.15), "table_metal": (0.03, 0.2), "ice_cubes": (0.06, 0.3), "under_glass": (0.12, 0.6)}  # (mean |d| sRGB, energy ratio band)
+    report = {}
+    for k, m in region.items():
+        d = np.abs(mine - ref)[m].mean()
+        ratio = lin_b[m].sum(0) / ref_lin[m].sum(0)
+        report[k] = (int(m.sum()), float(d), [float(x) for x in ratio])
+    print("glass-of-water vs the reference's render, by region (blocks, mean |d| in sRGB units, linear energy ratio RGB):", report)
+    for k, (n, d, ratio) in report.items():
+        assert n > 50 and d < limits[k][0], (k, d)
+        assert all(abs(r - 1.0) < limits[k][1] for r in ratio), (k, ratio)
+
+
+def test_classroom_sky_through_the_fog_is_attenuated_over_the_world_diameter(backend):
+    """integrator.cpp:146-151 on the scene that ships with it: classroom's JSON has global fog (sigma_t = 0.0221 / m, no absorption)
+    and the camera inside it.  A sky pixel seen through the window must come out as
+        L_fog = L_nofog * exp(-sigma_t * (d_window + world_diameter))  (+ a little in-scattered light),
+    world_diameter = 313.4 m for this scene's bounds, d_window = a few metres: a factor of 0.7e-3 ... 1.0e-3 before in-scattering.
+    The expected band comes from the scene's numbers, not from the oracle; without the rule the ratio is ~0.9.
+    (Why the reference's two classroom PNGs cannot serve as this pin — the factor is global, every photon of the scene comes from
+    the environment, and the HDRI's level is unknown — is worked out in DESIGN.md section 2.)"""
+    imgs = {}
+    for fog in (False, True):
+        hs, p, osc, _ = _load(backend, "scenes/classroom/vision_scene.json", 640, 360, mediums=fog)
+        if fog:
+            wd = hs.scene.lights[hs.scene.env_light].world_diameter
+            med = hs.scene.mediums[0]
+            sigma_t = (med.sigma_a[0] + med.sigma_s[0]) * med.scale
+            assert abs(wd - 313.4375) < 1e-3 and abs(sigma_t - 0.0221) < 1e-6
+        backend.reset_accum()
+        backend.render_batch(0, 128)
+        imgs[fog] = backend.download_accum()[..., :3].astype(np.float64)
+    lum = imgs[False] @ np.array([0.212671, 0.715160, 0.072169])
+    sky = lum >= np.quantile(lum, 0.985)          # the brightest 1.5 % of the fog-free picture: sky seen through the windows
+    ratio = imgs[True][sky].sum() / imgs[False][sky].sum()
+    lo, hi = np.exp(-sigma_t * (wd + 15.0)), np.exp(-sigma_t * wd) * 1.6   # up to 15 m to the window; up to +60 % in-scattered light
+    print("classroom sky through fog: ratio", ratio, "band", lo, hi)
+    assert lo < ratio < hi, (ratio, lo, hi)
 
 
 class _DevBuf:
