@@ -8,8 +8,9 @@
  *                                                                         base/import/scene_desc.cpp:37-62,
  *                                                                         base/import/node_desc.cpp (defaults),
  *                                                                         base/mgr/scene.cpp:16-35,79-91,165-187
- *   vmk_host_register_image  ocarina Image::load (image_pool.cpp:23-28)   decoded pixels are handed in by the caller;
- *                                                                         .hdr/.pfm are decoded natively
+ *   vmk_host_register_image  ocarina Image::load (image_pool.cpp:23-28)   decoded pixels handed in by the caller take precedence;
+ *                                                                         otherwise .png (8-bit), baseline .jpg and .hdr are decoded
+ *                                                                         natively (csrc/host/image_codec.h)
  * Error convention: 0 ok, negative on error, message via vmk_host_last_error() (thread-local).
  */
 #ifndef VMK_HOST_H

@@ -286,3 +286,37 @@ def test_sphere_tessellation_and_normal_slot(built, tmp_path):
     sc["materials"][-1]["param"]["mat1"] = dict(pr, name="p2")
     with pytest.raises(HostError, match="two lobe-set"):
         HostScene(_write(tmp_path, "mx2.json", sc), width=16, height=16)
+
+
+def test_native_image_decoders_match_pillow(built):
+    """csrc/host/image_codec.h (own PNG / baseline-JPEG decoders, IJG arithmetic) against Pillow on every image file the scenes
+    ship: byte-identical texture tables whichever side decodes, so goldens and GPU parity do not depend on the decoder."""
+    import hashlib
+    for scene, kw in (("scenes/classroom/vision_scene.json", {}), ("scenes/bathroom2/vision_scene.json", {"missing_assets": "standin"}),
+                      ("scenes/cbox/cbox_materials.json", {})):
+        digests = []
+        for decode in ("native", "pillow"):
+            hs = HostScene(os.path.join(ROOT, scene), width=32, height=32, decode=decode, **kw)
+            assert (decode == "pillow") == bool(hs.image_paths)
+            tex = C.string_at(hs.scene.tex_data, hs.scene.tex_bytes)
+            digests.append((hs.scene.n_textures, hs.scene.tex_bytes, hashlib.sha256(tex).hexdigest()))
+            hs.close()
+        assert digests[0] == digests[1] and digests[0][0] >= 1, (scene, digests)
+
+
+def test_native_decoders_refuse_what_they_do_not_decode(built, tmp_path):
+    from PIL import Image
+    sc = _cbox()
+    rng = np.random.default_rng(1)
+    img = Image.fromarray(rng.integers(0, 255, (24, 40, 3), dtype=np.uint8))
+    img.save(os.path.join(tmp_path, "prog.jpg"), progressive=True)
+    img.save(os.path.join(tmp_path, "base.jpg"), quality=90, subsampling=1)   # 4:2:2 -> the h2v1 triangle upsampler
+    img.convert("P").save(os.path.join(tmp_path, "pal.png"))
+    Image.fromarray(rng.integers(0, 255, (24, 40), dtype=np.uint8)).save(os.path.join(tmp_path, "gray.jpg"))
+    for fn, native in (("base.jpg", True), ("pal.png", True), ("gray.jpg", True), ("prog.jpg", False)):
+        sc["materials"][0]["param"]["color"] = {"fn": fn, "color_space": "srgb"}
+        path = _write(tmp_path, fn + ".json", sc)
+        hs = HostScene(path, width=16, height=16)          # falls back to Pillow + vmk_host_register_image where needed
+        assert bool(hs.image_paths) == (not native)
+        ref = HostScene(path, width=16, height=16, decode="pillow")
+        assert C.string_at(hs.scene.tex_data, hs.scene.tex_bytes) == C.string_at(ref.scene.tex_data, ref.scene.tex_bytes), fn

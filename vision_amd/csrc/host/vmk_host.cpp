@@ -9,6 +9,7 @@
 //   Geometry::update_instances / upload                                                      base/mgr/geometry.cpp:20-34,64-71
 #include "../../../include/vmk_host.h"
 #include "json.h"
+#include "image_codec.h"
 #include "rgb2spec_opt.h"
 
 #include <algorithm>
@@ -294,6 +295,14 @@ struct HostScene {
         auto reg = g_images.find(path);
         if (reg != g_images.end()) img = &reg->second;
         else if (ends_with(fn, ".hdr") && load_hdr(path, local)) img = &local;
+        else if ((ends_with(fn, ".png") || ends_with(fn, ".jpg") || ends_with(fn, ".jpeg")) && file_exists(path)) { // native decode (image_codec.h)
+            std::ifstream fi(path, std::ios::binary);
+            std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
+            vmk_img::Decoded dec = ends_with(fn, ".png") ? vmk_img::decode_png(bytes) : vmk_img::decode_jpeg(bytes);
+            if (!dec.error.empty()) fail("image '" + path + "': " + dec.error + " (decode it in the caller and hand the pixels to vmk_host_register_image)");
+            local.w = dec.w; local.h = dec.h; local.channels = dec.channels; local.is_float = false; local.u8.swap(dec.px);
+            img = &local;
+        }
         else if (allow_procedural && opt.procedural_env) { procedural_sky(local); img = &local; describe("image", "procedural_sky", fn + " (stand-in: file missing)"); }
         else if (opt.missing_assets == 1 && !file_exists(path)) { // declared stand-in for an asset stripped from the checkout: 1x1 mid-grey
             local.w = local.h = 1; local.channels = 3; local.is_float = false; local.u8 = {128, 128, 128, 255};

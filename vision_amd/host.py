@@ -1,8 +1,10 @@
 """Python binding of the C++ host (libvmk_host.so): Vision JSON scene -> flat vmk tables.
 
-The host keeps Vision's plugin namespace (category/type) and JSON schema; see include/vmk_host.h.  Image files are
-decoded here with Pillow and handed to the host (Vision decodes through ocarina's Image::load,
-src/base/mgr/image_pool.cpp:23-28); `.hdr` is decoded natively by the host.
+The host keeps Vision's plugin namespace (category/type) and JSON schema; see include/vmk_host.h.  Image files (8-bit PNG,
+baseline JPEG, Radiance .hdr) are decoded natively by the host (csrc/host/image_codec.h; Vision decodes through ocarina's
+Image::load, src/base/mgr/image_pool.cpp:23-28).  Only when the host reports a container it does not decode (progressive JPEG,
+16-bit PNG, ...) does this binding fall back to Pillow and hand the pixels over with vmk_host_register_image, as a C++ host that
+already holds decoded images would.
 """
 import ctypes as C
 import os
@@ -77,16 +79,23 @@ class HostScene:
     """Owns the host-side tables of one loaded scene (freed on close())."""
 
     def __init__(self, json_path, width=0, height=0, max_depth=-1, min_depth=-1, procedural_env=True,
-                 drop_unsupported_lights=False, lut_path=None, mediums=False, spectrum=None, missing_assets=None):
+                 drop_unsupported_lights=False, lut_path=None, mediums=False, spectrum=None, missing_assets=None, decode="native"):
         L = lib()
         json_path = os.path.abspath(json_path)
         self.json_path = json_path
-        self.image_paths = register_images_for(json_path)
+        self.image_paths = []
+        if decode == "pillow":
+            self.image_paths = register_images_for(json_path)
+        else:
+            L.vmk_host_clear_images()
         opt = _abi.HostOptions(width, height, max_depth, min_depth, int(procedural_env), int(drop_unsupported_lights),
                                (lut_path or DEFAULT_LUT_PATH).encode(), int(mediums),
                                {None: 0, "srgb": 1, "hero": 2}[spectrum], {None: 0, "fail": 0, "standin": 1}[missing_assets])
         h = C.c_void_p()
         rc = L.vmk_host_load_scene(json_path.encode(), C.byref(opt), C.byref(h))
+        if rc != 0 and decode == "native" and "vmk_host_register_image" in _err():  # a container the native decoders do not handle
+            self.image_paths = register_images_for(json_path)
+            rc = L.vmk_host_load_scene(json_path.encode(), C.byref(opt), C.byref(h))
         if rc != 0:
             raise HostError(_err())
         self._h = h
