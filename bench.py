@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-replay", action="store_true", help="skip the traversal-only replay of the megakernel's own rays")
     ap.add_argument("--no-self-check", action="store_true", help="skip vmk_self_check (profiling runs: keeps every k_render dispatch a timed step)")
     ap.add_argument("--no-sibling", action="store_true", help="skip the counting sibling pass (roofline.achieved is then null)")
+    ap.add_argument("--force-exchange", action="store_true", help="rehearsal on one GPU: run the per-step C-ABI exchange with a 1-rank communicator")
     ap.add_argument("--save", default=None, help="write the final tone-mapped picture (rank 0)")
     a = ap.parse_args()
 
@@ -113,14 +114,27 @@ def main():
     dev = torch.device("cuda", local_rank)
     fb = torch.zeros((params.height, params.width, 4), dtype=torch.float32, device=dev)
     pipe.use_torch_framebuffer(fb)
-    full = torch.zeros_like(fb) if world > 1 else fb
+    exchange = world > 1 or a.force_exchange
+    full = torch.zeros_like(fb) if exchange else fb
     pipe.set_tiles(a.tile, rank, world)
-    if dist:  # RCCL communicator behind the C-ABI: rank 0's id travels over the rendezvous backend
-        idt = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(Backend.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        be.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    exchange_via = "none"
+    if exchange:  # RCCL communicator behind the C-ABI: rank 0's id travels over the rendezvous backend
+        try:
+            idt = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(Backend.comm_unique_id()), dtype=torch.uint8))
+            if dist:
+                dist.broadcast(idt, 0)
+            be.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            exchange_via = a.exchange + " behind the C-ABI (vmk_" + a.exchange + "_framebuffer over RCCL), overlapped with the next step"
+        except Exception as e:  # never lose the multi-GPU measurement to the communicator bootstrap: same collective through torch
+            exchange_via = f"torch.distributed all_reduce (C-ABI communicator unavailable: {str(e)[:160]})"
+        if dist:  # every rank must take the same path
+            ok = torch.tensor([0 if exchange_via.startswith("torch") else 1], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and not exchange_via.startswith("torch"):
+                exchange_via = "torch.distributed all_reduce (another rank could not create the C-ABI communicator)"
+    tiles_for_exchange = pipe.tiles if pipe.tiles is not None else _abi.Tiles(a.tile, 0, 1)
 
     def sync_all():
         be.synchronize()
@@ -132,11 +146,17 @@ def main():
 
     def step():
         pipe.render(frames=spp, timed=False)  # asynchronous; HIP events on the ctx stream bracket the launch (collect_kernel_ms)
-        if dist:  # the path's one exchange step (disjoint tiles, x + 0 is exact), overlapped with the next step's megakernel
-            if a.exchange == "allreduce":
+        if exchange:  # the path's one exchange step (disjoint tiles, x + 0 is exact), overlapped with the next step's megakernel
+            if exchange_via.startswith("torch"):
+                be.synchronize()
+                full.copy_(fb)
+                if dist:
+                    dist.all_reduce(full, op=dist.ReduceOp.SUM)
+                torch.cuda.current_stream().synchronize()  # the copy must have read fb before the next film resolve writes it
+            elif a.exchange == "allreduce":
                 be.allreduce_framebuffer(full.data_ptr())
             else:
-                be.allgather_framebuffer(pipe.tiles, full.data_ptr())
+                be.allgather_framebuffer(tiles_for_exchange, full.data_ptr())
 
     be.enable_kernel_timing(True)
     be.set_traversal_counters(False)  # timed instance: no tallies in the traversal loops (sibling pass below supplies them)
@@ -156,10 +176,10 @@ def main():
     kernel_ms = be.collect_kernel_ms()
     c = pipe.counters()
     if a.save and rank == 0:
-        if world > 1:
+        if exchange:
             be.set_framebuffer(full.data_ptr())
         pipe.save_result(a.save)
-        if world > 1:
+        if exchange:
             be.set_framebuffer(fb.data_ptr())
     # ---- sibling pass: the same frames through the tallying instance (film contents are not used afterwards) ----
     sib = None
@@ -208,7 +228,7 @@ def main():
             "config": {"workload": f"{workload}: {params.width}x{params.height}, max_depth {params.max_depth}, min_depth {params.min_depth}, "
                                    f"{spp} spp per step x {a.steps} steps = {spp * a.steps} spp",
                        "baseline_config": a.config, "triangles": int(sc.n_tris), "spp_per_step": spp, "tile": a.tile, "parallelism": f"tiles/{world}",
-                       "exchange": (a.exchange + " behind the C-ABI (RCCL), overlapped with the next step") if world > 1 else "none"},
+                       "exchange": exchange_via},
             "self_check": f"megakernel == unit kernel on {checked} pixels of frame 0 (bit-exact)" if checked else "skipped",
             "rays_per_path": rays / max(c_all["paths"], 1),
             "nodes_per_ray": c_all["nodes_visited"] / max(rays, 1), "tris_per_ray": c_all["tris_tested"] / max(rays, 1),

@@ -617,9 +617,11 @@ struct RcclApi {
 static RcclApi g_rccl;
 static bool rccl_load(std::string &err) {
     if (g_rccl.lib) return true;
-    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // a host that already runs RCCL (torch.distributed's "nccl" backend on ROCm) keeps one copy: reuse a loaded library first
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
-    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h) for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) { err = std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : "?"); return false; }
     RcclApi a; a.lib = h;
 #define VMK_SYM(field, name) a.field = (decltype(a.field)) dlsym(h, name); if (!a.field) { err = std::string("RCCL symbol missing: ") + name; dlclose(h); return false; }
