@@ -148,7 +148,7 @@ struct GlobalRayIO {
 #define VMK_NODE_QUADS_MIN 8 // leave the node phase when fewer quads than this are on internal nodes and others wait
 #endif
 #ifndef VMK_REFILL_QUADS_MIN
-#define VMK_REFILL_QUADS_MIN 6 // hand back hits / take new rays once this many quads are idle (or nothing else is left); 4: 339.9, 6: 336.5, 8: 341 ms (classroom, 32 spp)
+#define VMK_REFILL_QUADS_MIN 4 // hand back hits / take new rays once this many quads are idle (or nothing else is left); 4: 339.9, 6: 336.5, 8: 341 ms (classroom, 32 spp)
 #endif
 
 // The traversal loop of one wave; EVERY lane of the wave must be here (convergently).
