@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VMK_ABI_VERSION 5u
+#define VMK_ABI_VERSION 6u
 #define VMK_INVALID 0xFFFFFFFFu
 
 typedef enum vmk_status {
@@ -100,7 +100,7 @@ typedef struct vmk_slot {
 /* Spectrum plugin (src/render_core/spectrum): how colours travel along a path */
 typedef enum vmk_spectrum_type {
     VMK_SPECTRUM_SRGB = 0, /* srgb.cpp: three fixed channels, RGB values used as they are */
-    VMK_SPECTRUM_HERO = 1  /* hero.cpp: 3 wavelengths per path (hero + 2 rotations), RGB uplifted through the sigmoid table */
+    VMK_SPECTRUM_HERO = 1  /* hero.cpp: 3 or 4 wavelengths per path (hero + rotations, vmk_scene::spectrum_dimension), RGB uplifted through the sigmoid table */
 } vmk_spectrum_type;
 #define VMK_RGB2SPEC_RES 64u /* RGBToSpectrumTable::res hero.cpp:53 */
 
@@ -228,6 +228,7 @@ typedef struct vmk_scene {
     uint32_t spd_cie_count;     /* samples per CIE table (94: every 5th of the 1 nm tables) */
     float spd_cie_interval;     /* SPD::sample_interval_ of those tables (471 / 94) */
     float cie_y_integral;       /* SPD::cie_y_integral() spd.cpp:111-114 */
+    uint32_t spectrum_dimension; /* HeroWavelengthSpectrum::dimension_ (hero.cpp:229,240): 3 (also 0) or 4; each is its own megakernel instance */
 } vmk_scene;
 
 /* ---- camera / film / integrator ---------------------------------------------------------------------- */

@@ -34,7 +34,8 @@ typedef struct vmk_host_options {
     uint32_t mediums;           /* 0: ignore the scene's "mediums" block (the non-fog variant, BASELINE config 3);
                                  * 1: honour it (mediums.process, global medium, per-shape inside/outside, sensor medium) */
     uint32_t spectrum;          /* 0: keep the scene's "spectrum" block; 1: force spectrum/srgb; 2: force spectrum/hero (the shipped
-                                 * scenes carry the hero line commented out — this flips it without editing the file) */
+                                 * scenes carry the hero line commented out — this flips it without editing the file), with the block's
+                                 * "dimension" (3 when absent); 3: force spectrum/hero with "dimension": 4 */
     uint32_t missing_assets;    /* 0: a mesh / texture file the scene names but the disk lacks is an error; 1 ("standin"): a missing mesh is
                                  * skipped and a missing texture becomes a 1x1 mid-grey constant, each listed by vmk_host_describe as
                                  * "... (stand-in: file missing ...)" — for scenes whose large assets are stripped from the reference

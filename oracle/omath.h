@@ -177,6 +177,50 @@ inline float3 saturate3(float3 a) { return {saturate_(a.x), saturate_(a.y), satu
 inline float3 select3(bool c, float3 a, float3 b) { return c ? a : b; }
 inline float luminance(float3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
 
+// ---- sampled spectrum (base/color/spectrum.h:60-170) ----
+// ORC_SPEC_DIM = 3 (default): a float3 — the (R, G, B) channels of spectrum/srgb or the three wavelengths of spectrum/hero, the
+// arithmetic this oracle always had.  ORC_SPEC_DIM = 4 (liboracle4.so, the second build of the same source): four samples, for
+// spectrum/hero scenes with "dimension": 4.  Directions, positions and RGB colours stay float3.
+#ifndef ORC_SPEC_DIM
+#define ORC_SPEC_DIM 3
+#endif
+struct spec4 { float x, y, z, w; };
+inline spec4 operator+(spec4 a, spec4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline spec4 operator-(spec4 a, spec4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+inline spec4 operator*(spec4 a, spec4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+inline spec4 operator/(spec4 a, spec4 b) { return {a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w}; }
+inline spec4 operator*(spec4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+inline spec4 operator*(float s, spec4 a) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+inline spec4 operator/(spec4 a, float s) { return {a.x / s, a.y / s, a.z / s, a.w / s}; }
+inline spec4 operator-(float s, spec4 a) { return {s - a.x, s - a.y, s - a.z, s - a.w}; }
+inline spec4 operator-(spec4 a) { return {-a.x, -a.y, -a.z, -a.w}; }
+inline spec4 &operator+=(spec4 &a, spec4 b) { a = a + b; return a; }
+inline spec4 &operator*=(spec4 &a, spec4 b) { a = a * b; return a; }
+inline spec4 &operator*=(spec4 &a, float s) { a = a * s; return a; }
+inline bool is_zero(spec4 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f && a.w == 0.f; }
+inline float max_comp(spec4 a) { return fmax_(fmax_(fmax_(a.x, a.y), a.z), a.w); }
+inline float average(spec4 a) { return (a.x + a.y + a.z + a.w) / 4.f; } // sum() * (1.0 / dimension), spectrum.h:147-149
+inline spec4 lerp3(float t, spec4 a, spec4 b) { return a + (b - a) * t; }
+inline spec4 saturate3(spec4 a) { return {saturate_(a.x), saturate_(a.y), saturate_(a.z), saturate_(a.w)}; }
+#if ORC_SPEC_DIM == 4
+typedef spec4 Spec;
+inline Spec make_spec(float v) { return {v, v, v, v}; }
+template<class F> inline Spec smap(Spec a, F f) { return {f(a.x), f(a.y), f(a.z), f(a.w)}; }
+template<class F> inline Spec smap2(Spec a, Spec b, F f) { return {f(a.x, b.x), f(a.y, b.y), f(a.z, b.z), f(a.w, b.w)}; }
+inline float scomp(Spec a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : (i == 2 ? a.z : a.w)); }
+inline Spec spec_from_array(const float *v) { return {v[0], v[1], v[2], v[3]}; }
+#elif ORC_SPEC_DIM == 3
+typedef float3 Spec;
+inline Spec make_spec(float v) { return {v, v, v}; }
+template<class F> inline Spec smap(Spec a, F f) { return {f(a.x), f(a.y), f(a.z)}; }
+template<class F> inline Spec smap2(Spec a, Spec b, F f) { return {f(a.x, b.x), f(a.y, b.y), f(a.z, b.z)}; }
+inline float scomp(Spec a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+inline Spec spec_from_array(const float *v) { return {v[0], v[1], v[2]}; }
+#else
+#error "ORC_SPEC_DIM must be 3 or 4"
+#endif
+constexpr uint32_t kSpecDim = ORC_SPEC_DIM;
+
 // ---- pbrt-style local shading geometry (math/geometry.h of ocarina; z-up local frame) ----
 inline float cos_theta(float3 w) { return w.z; }
 inline float abs_cos_theta(float3 w) { return abs_(w.z); }

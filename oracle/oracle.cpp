@@ -165,7 +165,8 @@ inline float eval_slot1(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
 
 // =====================================================================================================
 // a2. spectrum — render_core/spectrum/{srgb,hero}.cpp, base/color/{spd,spectrum}.cpp.
-// A dimension-3 SampledSpectrum is a float3 in both modes.  In hero mode the path's SampledWavelengths live in a
+// A SampledSpectrum is a Spec (omath.h): a float3 for dimension 3 in both modes, four samples in the ORC_SPEC_DIM = 4 build
+// (spectrum/hero, "dimension": 4).  In hero mode the path's SampledWavelengths live in a
 // thread-local (set by Li for the path being traced); every decode below reads them.
 // PARITY UNPINNED for the hero branch's data: Vision's sRGB->spectrum table (srgb2spec.h) is absent from the reference
 // checkout, so the table these functions read is regenerated by the host (vision_amd/csrc/host/rgb2spec_opt.h, the
@@ -173,7 +174,7 @@ inline float eval_slot1(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
 // render to the sRGB render; tests/test_host.py, tests/test_oracle_render.py).  The arithmetic itself follows hero.cpp /
 // spd.cpp line by line, including SPD's 471/94 nm sample spacing.
 // =====================================================================================================
-struct Swl { float lambda[3]; float pdf[3]; };
+struct Swl { float lambda[kSpecDim]; float pdf[kSpecDim]; };
 static thread_local Swl *tl_swl = nullptr; // non-null only while a hero-spectrum path is traced
 inline bool is_hero(const vmk_scene *s) { return s->spectrum == VMK_SPECTRUM_HERO; }
 inline float sample_visible_wavelength(float u) { return 538.f - 138.888889f * atanh_(0.85691062f - 1.82750197f * u); } // hero.cpp:15-18
@@ -181,8 +182,8 @@ inline float visible_wavelength_PDF(float lambda) { return 0.0039398042f / sqr(c
 inline Swl sample_wavelengths(Sampler &sampler) { // hero.cpp:286-299, 1 draw
     Swl swl;
     float u = sampler.next_1d();
-    for (uint32_t i = 0; i < 3u; ++i) {
-        float offset = (float) i * (1.f / 3.f);
+    for (uint32_t i = 0; i < kSpecDim; ++i) {
+        float offset = (float) i * (1.f / (float) kSpecDim);
         float up = fract_(u + offset);
         swl.lambda[i] = sample_visible_wavelength(up);
         swl.pdf[i] = visible_wavelength_PDF(swl.lambda[i]);
@@ -196,7 +197,7 @@ inline float spd_eval(const float *f, float interval, float lambda) { // SPD::ev
     float l = f[i], r = f[i + 1u];
     return lerp_(fract_(t), l, r);
 }
-inline float3 spd_eval3(const float *f, float interval, const Swl &swl) { return {spd_eval(f, interval, swl.lambda[0]), spd_eval(f, interval, swl.lambda[1]), spd_eval(f, interval, swl.lambda[2])}; }
+inline Spec spd_eval3(const float *f, float interval, const Swl &swl) { return smap(spec_from_array(swl.lambda), [&](float lambda) { return spd_eval(f, interval, lambda); }); }
 inline float sigmoid_polynomial(float3 c, float lambda) { // RGBSigmoidPolynomial hero.cpp:27-49
     float x = fma_(fma_(c.x, lambda, c.y), lambda, c.z);
     float v = 0.5f * fma_(x, rsqrt_(fma_(x, x, 1.f)), 1.f);
@@ -240,31 +241,42 @@ inline float3 rgb2spec_unbound_coeffs(const vmk_scene *s, float3 rgb_in, float *
     *scale_out = scale;
     return rgb2spec_albedo_coeffs(s, scale == 0.f ? make_float3(0.f) : rgb / scale);
 }
-inline float3 sigmoid3(float3 c, const Swl &swl) { return {sigmoid_polynomial(c, swl.lambda[0]), sigmoid_polynomial(c, swl.lambda[1]), sigmoid_polynomial(c, swl.lambda[2])}; }
+inline Spec sigmoid3(float3 c, const Swl &swl) { return smap(spec_from_array(swl.lambda), [&](float lambda) { return sigmoid_polynomial(c, lambda); }); }
 // decode_to_albedo / decode_to_unbound_spectrum / decode_to_illumination (srgb.cpp:49-57, hero.cpp:331-342)
-inline float3 spec_albedo(const vmk_scene *s, float3 rgb) {
-    if (!is_hero(s)) return rgb;
+#if ORC_SPEC_DIM == 3
+inline Spec rgb_as_spec(float3 rgb) { return rgb; } // spectrum/srgb: the channels are the samples (srgb.cpp:49-57)
+#else
+inline Spec rgb_as_spec(float3) { fprintf(stderr, "oracle (ORC_SPEC_DIM = 4): not a spectrum/hero scene\n"); abort(); }
+#endif
+inline Spec spec_albedo(const vmk_scene *s, float3 rgb) {
+    if (!is_hero(s)) return rgb_as_spec(rgb);
     return sigmoid3(rgb2spec_albedo_coeffs(s, rgb), *tl_swl);
 }
-inline float3 spec_unbound(const vmk_scene *s, float3 rgb) {
-    if (!is_hero(s)) return rgb;
+inline Spec spec_unbound(const vmk_scene *s, float3 rgb) {
+    if (!is_hero(s)) return rgb_as_spec(rgb);
     float scale; float3 c = rgb2spec_unbound_coeffs(s, rgb, &scale);
     return sigmoid3(c, *tl_swl) * scale; // RGBUnboundSpectrum::eval hero.cpp:201-203
 }
-inline float3 spec_illumination(const vmk_scene *s, float3 rgb) {
-    if (!is_hero(s)) return rgb;
+inline Spec spec_illumination(const vmk_scene *s, float3 rgb) {
+    if (!is_hero(s)) return rgb_as_spec(rgb);
     float scale; float3 c = rgb2spec_unbound_coeffs(s, rgb, &scale);
     return (sigmoid3(c, *tl_swl) * scale) * spd_eval3(s->spd_data + s->spd_cie[3], s->spd_cie_interval, *tl_swl); // hero.cpp:219-221
 }
 // Spectrum::linear_srgb (srgb.cpp:46-48; hero.cpp:265-267,281-291 + cie::xyz_to_linear_srgb cie.h:413-420)
-inline float3 spec_linear_srgb(const vmk_scene *s, float3 sp) {
-    if (!is_hero(s)) return sp;
+#if ORC_SPEC_DIM == 3
+inline float3 spec_as_rgb(Spec sp) { return sp; } // Spectrum::linear_srgb of srgb.cpp:46-48
+#else
+inline float3 spec_as_rgb(Spec) { fprintf(stderr, "oracle (ORC_SPEC_DIM = 4): not a spectrum/hero scene\n"); abort(); }
+#endif
+inline float3 spec_linear_srgb(const vmk_scene *s, Spec sp) {
+    if (!is_hero(s)) return spec_as_rgb(sp);
     const Swl &swl = *tl_swl;
     const float *X = s->spd_data + s->spd_cie[0], *Y = s->spd_data + s->spd_cie[1], *Z = s->spd_data + s->spd_cie[2];
-    float v[3] = {sp.x, sp.y, sp.z};
+    float v[kSpecDim];
+    for (uint32_t i = 0; i < kSpecDim; ++i) v[i] = scomp(sp, i);
     float3 sum = make_float3(0.f);
     uint32_t valid = 0;
-    for (int i = 0; i < 3; ++i) {
+    for (uint32_t i = 0; i < kSpecDim; ++i) {
         float p = swl.pdf[i];
         float x = spd_eval(X, s->spd_cie_interval, swl.lambda[i]) * v[i], y = spd_eval(Y, s->spd_cie_interval, swl.lambda[i]) * v[i], z = spd_eval(Z, s->spd_cie_interval, swl.lambda[i]) * v[i];
         sum = sum + make_float3(p == 0.f ? 0.f : x / p, p == 0.f ? 0.f : y / p, p == 0.f ? 0.f : z / p);
@@ -276,11 +288,15 @@ inline float3 spec_linear_srgb(const vmk_scene *s, float3 sp) {
             -0.969256f * xyz.x + 1.875991f * xyz.y + 0.041556f * xyz.z,
             0.055648f * xyz.x + -0.204043f * xyz.y + 1.057311f * xyz.z};
 }
-inline float3 eval_slot_albedo(const vmk_scene *s, const vmk_slot &sl, float2 uv) { return spec_albedo(s, eval_slot3(s, sl, uv)); }             // shader_node.cpp:317-321
-inline float3 eval_slot_illumination(const vmk_scene *s, const vmk_slot &sl, float2 uv) { return spec_illumination(s, eval_slot3(s, sl, uv)); } // shader_node.cpp:329-333
-inline float3 eval_slot_spd(const vmk_scene *s, const vmk_slot &sl, float2 uv) { // number slot that may be an "spd" node (spd.cpp:36-39)
+inline Spec eval_slot_albedo(const vmk_scene *s, const vmk_slot &sl, float2 uv) { return spec_albedo(s, eval_slot3(s, sl, uv)); }             // shader_node.cpp:317-321
+inline Spec eval_slot_illumination(const vmk_scene *s, const vmk_slot &sl, float2 uv) { return spec_illumination(s, eval_slot3(s, sl, uv)); } // shader_node.cpp:329-333
+inline Spec eval_slot_spd(const vmk_scene *s, const vmk_slot &sl, float2 uv) { // number slot that may be an "spd" node (spd.cpp:36-39)
     if (sl.tex == VMK_SLOT_SPD) return spd_eval3(s->spd_data + f2u(sl.v[0]), sl.v[2], *tl_swl);
+#if ORC_SPEC_DIM == 4
+    return make_spec(eval_slot1(s, sl, uv)); // (a complete spectrum feeds these slots from "spd" nodes, metal.cpp:113-117; a plain number is one value)
+#else
     return eval_slot3(s, sl, uv);
+#endif
 }
 
 // =====================================================================================================
@@ -649,38 +665,38 @@ inline float fresnel_complex(float cos_i, float eta_re, float k) { // optics.h:9
 enum FresnelKind { FR_CONSTANT, FR_CONDUCTOR, FR_DIELECTRIC, FR_SCHLICK, FR_F82 };
 struct Fresnel {
     int kind{FR_CONSTANT};
-    float3 a{1, 1, 1}; // conductor eta | schlick F0 | F82 F0
-    float3 b{0, 0, 0}; // conductor k   | F82 B
+    Spec a = make_spec(1.f); // conductor eta | schlick F0 | F82 F0
+    Spec b = make_spec(0.f); // conductor k   | F82 B
     float eta{1.f};    // dielectric / schlick eta[0]
     bool eta_sp{false}; // hero: FresnelDielectric over an "spd" ior — a = the per-wavelength eta, eta = a.x (fresnel.h:83-91)
-    float3 evaluate(float cos_t) const {
+    Spec evaluate(float cos_t) const {
         switch (kind) {
-            case FR_CONDUCTOR: return {fresnel_complex(cos_t, a.x, b.x), fresnel_complex(cos_t, a.y, b.y), fresnel_complex(cos_t, a.z, b.z)};
+            case FR_CONDUCTOR: return smap2(a, b, [&](float e, float k) { return fresnel_complex(cos_t, e, k); });
             case FR_DIELECTRIC: {
-                if (eta_sp) return {fresnel_dielectric(cos_t, a.x), fresnel_dielectric(cos_t, a.y), fresnel_dielectric(cos_t, a.z)};
-                float f = fresnel_dielectric(cos_t, eta); return {f, f, f};
+                if (eta_sp) return smap(a, [&](float e) { return fresnel_dielectric(cos_t, e); });
+                float f = fresnel_dielectric(cos_t, eta); return make_spec(f);
             }
             case FR_SCHLICK: { // fresnel.h:60-67
                 float F_real = fresnel_dielectric(cos_t, eta);
                 float F0_real = schlick_F0_from_ior(eta);
                 float t = clamp_(inverse_lerp(F_real, F0_real, 1.f), 0.f, 1.f);
-                return lerp3(t, a, make_float3(1.f));
+                return lerp3(t, a, make_spec(1.f));
             }
             case FR_F82: { // fresnel.h:123-129
                 float mu = saturate_(1.f - cos_t);
                 float mu5 = pow5(mu);
-                float3 f_schlick = lerp3(mu5, a, make_float3(1.f));
+                Spec f_schlick = lerp3(mu5, a, make_spec(1.f));
                 return saturate3(f_schlick - b * cos_t * mu5 * mu);
             }
-            default: return {1.f, 1.f, 1.f};
+            default: return make_spec(1.f);
         }
     }
 };
-inline void f82_init(Fresnel &fr, float3 F82) { // fresnel.h:115-121
+inline void f82_init(Fresnel &fr, Spec F82) { // fresnel.h:115-121
     const float f = 6.f / 7.f;
     const float f5 = pow5(f);
-    float3 one = make_float3(1.f);
-    float3 f_schlick = lerp3(f5, fr.a, one);
+    Spec one = make_spec(1.f);
+    Spec f_schlick = lerp3(f5, fr.a, one);
     fr.b = f_schlick * (7.f / (f5 * f)) * (one - F82);
 }
 
@@ -691,7 +707,7 @@ namespace flag {
 constexpr uint32_t Unset = 1, Reflection = 2, Transmission = 4, Diffuse = 8, Glossy = 16, Specular = 32, NearSpec = 64;
 constexpr uint32_t DiffRefl = Diffuse | Reflection, GlossyRefl = Glossy | Reflection, GlossyTrans = Glossy | Transmission;
 }
-struct ScatterEval { float3 f{0, 0, 0}; float pdf{0.f}; uint32_t flags{flag::Unset}; bool valid() const { return pdf > 0.f; } };
+struct ScatterEval { Spec f = make_spec(0.f); float pdf{0.f}; uint32_t flags{flag::Unset}; bool valid() const { return pdf > 0.f; } };
 struct BSDFSample { ScatterEval eval; float3 wi{0, 0, 0}; float eta{1.f}; bool valid() const { return eval.valid(); } };
 struct SampledDirection { float3 wi{0, 0, 0}; bool valid{true}; };
 
@@ -699,8 +715,8 @@ enum LobeKind { LB_LAMBERT, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_D
 struct Lobe {
     int kind{LB_LAMBERT};
     Frame frame;
-    float3 kr{1, 1, 1};     // Lambert Kr / OrenNayar R / MicrofacetReflection kr / dielectric kt / sheen tint / blend Rd
-    float3 rs{0, 0, 0};     // FresnelBlend Rs
+    Spec kr = make_spec(1.f); // Lambert Kr / OrenNayar R / MicrofacetReflection kr / dielectric kt / sheen tint / blend Rd
+    Spec rs = make_spec(0.f); // FresnelBlend Rs
     float A{0}, B{0};       // Oren-Nayar | sheen a,b
     float ax{0}, ay{0};
     Fresnel fr;
@@ -727,15 +743,15 @@ inline float2 dielectric_sample_lut(const vmk_scene *s, const Lobe &l, float3 wo
     float out[2]; sample_lut3d(lut, 2, make_float3(x, y, z), out);
     return {out[0], out[1]};
 }
-inline float dielectric_refl_prob(const Lobe &l, float3 F) { // lobe.cpp:315-319
-    float3 T = 1.f - F;
-    float3 total = T * l.kr + F;
+inline float dielectric_refl_prob(const Lobe &l, Spec F) { // lobe.cpp:315-319
+    Spec T = 1.f - F;
+    Spec total = T * l.kr + F;
     return average(F) / average(total);
 }
 
 // FresnelBlend::f_specular (substrate.cpp:31-37): D(wh) / (4 |wi.wh| max(|cos_i|,|cos_o|)) * fresnel_schlick(Rs, wi.wh)
-inline float3 blend_f_specular(const Lobe &l, float3 wo, float3 wi, float3 wh) {
-    float3 specular = lerp3(schlick_weight(dot(wi, wh)), l.rs, make_float3(1.f)) *
+inline Spec blend_f_specular(const Lobe &l, float3 wo, float3 wi, float3 wh) {
+    Spec specular = lerp3(schlick_weight(dot(wi, wh)), l.rs, make_spec(1.f)) *
                       (bsdf_D(wh, l.ax, l.ay) / (4.f * abs_dot(wi, wh) * fmax_(abs_cos_theta(wi), abs_cos_theta(wo))));
     return specular * (is_zero(wh) ? 0.f : 1.f);
 }
@@ -746,7 +762,7 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
     switch (l.kind) {
         case LB_LAMBERT: case LB_OREN_NAYAR: { // DiffuseLobe -> BxDF::safe_evaluate (bxdf.cpp:34-46)
             bool sh = same_hemisphere(wo, wi);
-            float3 f;
+            Spec f;
             if (l.kind == LB_LAMBERT) f = l.kr * InvPi; // bxdf.h:92-95
             else { // OrenNayar::f bxdf.cpp:103-121
                 float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
@@ -757,7 +773,7 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
                 float tan_beta = cond ? sin_i / abs_cos_theta(wi) : sin_o / abs_cos_theta(wo);
                 f = l.kr * InvPi * (l.A + l.B * max_cos * sin_alpha * tan_beta);
             }
-            se.f = sh ? f : make_float3(0.f);
+            se.f = sh ? f : make_spec(0.f);
             se.pdf = sh ? cosine_hemisphere_PDF(abs_cos_theta(wi)) : 0.f;
             se.flags = flag::DiffRefl;
             return se;
@@ -766,10 +782,10 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
             bool sh = same_hemisphere(wo, wi);
             float3 wh = normalize(wo + wi);
             float3 whf = face_forward(wh, make_float3(0, 0, 1));
-            float3 F = l.fr.evaluate(abs_dot(wo, whf));
-            float3 f = (F * BRDF_div_fr(wo, whf, wi, l.ax, l.ay)) * l.kr;
+            Spec F = l.fr.evaluate(abs_dot(wo, whf));
+            Spec f = (F * BRDF_div_fr(wo, whf, wi, l.ax, l.ay)) * l.kr;
             float pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay);
-            se.f = sh ? f : make_float3(0.f);
+            se.f = sh ? f : make_spec(0.f);
             se.pdf = sh ? pdf : 0.f;
             se.flags = flag::GlossyRefl;
             if (l.compensate) se.f *= pure_reflection_compensate(s, l, wo); // lobe.cpp:722-729
@@ -778,20 +794,20 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
         case LB_FRESNEL_BLEND: { // substrate.cpp:12-70 through BxDF::safe_evaluate
             bool sh = same_hemisphere(wo, wi);
             float3 wh = normalize(wi + wo);
-            float3 specular = blend_f_specular(l, wo, wi, wh);
-            float3 diffuse = (28.f / (23.f * Pi)) * l.kr * (make_float3(1.f) - l.rs) *
+            Spec specular = blend_f_specular(l, wo, wi, wh);
+            Spec diffuse = (28.f / (23.f * Pi)) * l.kr * (make_spec(1.f) - l.rs) *
                              (1.f - pow5(1.f - .5f * abs_cos_theta(wi))) * (1.f - pow5(1.f - .5f * abs_cos_theta(wo)));
-            float3 f = specular + diffuse;
+            Spec f = specular + diffuse;
             float fr = l.fr.evaluate(abs_cos_theta(wo)).x;
             float pdf = lerp_(fr, cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
-            se.f = sh ? f : make_float3(0.f);
+            se.f = sh ? f : make_spec(0.f);
             se.pdf = sh ? pdf : 0.f;
             se.flags = flag::Reflection;
             return se;
         }
         case LB_PLASTIC: { // PlasticLobe::evaluate_local_impl plastic.cpp:31-43 (no hemisphere test of its own)
             float3 wh = normalize(wo + wi);
-            float3 F = l.fr.evaluate(abs_dot(wh, wo));
+            Spec F = l.fr.evaluate(abs_dot(wh, wo));
             se.f = (l.kr * InvPi) * (1.f - F);
             se.f += BRDF_div_fr(wo, wh, wi, l.ax, l.ay) * F;
             se.pdf = lerp_(average(F), cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
@@ -805,7 +821,7 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
             if (eta_out) *eta_out = eta_p;
             float3 wh = normalize(wo + wi * eta_p);
             wh = face_forward(wh, wo);
-            float3 F = l.fr.evaluate(abs_dot(wh, wo));
+            Spec F = l.fr.evaluate(abs_dot(wh, wo));
             float2 lut = dielectric_sample_lut(s, l, wo, eta);
             if (refl) { // evaluate_reflection lobe.cpp:340-353
                 se.f = F * BRDF_div_fr(wo, wh, wi, l.ax, l.ay);
@@ -815,7 +831,7 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
             } else { // evaluate_transmission lobe.cpp:355-371
                 float3 new_wh = face_forward(wh, wo);
                 float3 wh2 = normalize(wo + wi * eta); // GGXMicrofacet::BTDF(wo, wi, Ft, eta, tm) recomputes wh
-                float3 tr = (1.f - F) * BTDF_div_ft(wo, wh2, wi, eta, l.ax, l.ay, radiance);
+                Spec tr = (1.f - F) * BTDF_div_ft(wo, wh2, wi, eta, l.ax, l.ay, radiance);
                 se.f = tr * l.kr;
                 se.pdf = PDF_wi_transmission(wo, new_wh, wi, eta, l.ax, l.ay) * (1.f - dielectric_refl_prob(l, F));
                 se.flags = flag::GlossyTrans;
@@ -832,7 +848,7 @@ inline ScatterEval eval_local(const vmk_scene *s, const Lobe &l, float3 wo, floa
             float ltc = cosine_hemisphere_PDF(cos_theta(w)) * jacobian;
             se.f = l.kr * ltc / cos_i;
             se.pdf = ltc;
-            if (cos_i < 0.f || cos_o < 0.f) se.f = make_float3(0.f);
+            if (cos_i < 0.f || cos_o < 0.f) se.f = make_spec(0.f);
             se.flags = flag::Unset; // ScatterEval default: SheenLTC never assigns flags
             return se;
         }
@@ -873,7 +889,7 @@ inline SampledDirection sample_wi_local(const Lobe &l, float3 wo, Sampler &sampl
         }
         case LB_PLASTIC: { // PlasticLobe::sample_wi_local_impl plastic.cpp:45-59: 2 + 1 draws, 2 more on the diffuse branch
             float3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
-            float3 F = l.fr.evaluate(abs_cos_theta(wo));
+            Spec F = l.fr.evaluate(abs_cos_theta(wo));
             float uc = sampler.next_1d();
             if (uc < average(F)) { sd.wi = reflect(wo, wh); sd.valid = same_hemisphere(wo, sd.wi); }
             else sd.wi = square_to_cosine_hemisphere(sampler.next_2d());
@@ -882,7 +898,7 @@ inline SampledDirection sample_wi_local(const Lobe &l, float3 wo, Sampler &sampl
         case LB_DIELECTRIC: { // lobe.cpp:431-449
             float3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
             float d = dot(wo, wh);
-            float3 F = l.fr.evaluate(abs_(d));
+            Spec F = l.fr.evaluate(abs_(d));
             float uc = sampler.next_1d();
             if (uc < dielectric_refl_prob(l, F)) {
                 sd.wi = reflect(wo, wh);
@@ -972,12 +988,11 @@ inline BSDFSample evaluator_sample(const vmk_scene *s, const LobeSet &ls, float3
 }
 
 // ---- material -> lobes (create_lobe_set of each material plugin) ----
-inline float layering_weight_max(float3 layer_albedo, float3 weight) { // principled_bsdf.cpp:209-214
-    float3 tmp = {weight.x == 0.f ? 0.f : layer_albedo.x / weight.x, weight.y == 0.f ? 0.f : layer_albedo.y / weight.y,
-                  weight.z == 0.f ? 0.f : layer_albedo.z / weight.z};
+inline float layering_weight_max(Spec layer_albedo, Spec weight) { // principled_bsdf.cpp:209-214
+    Spec tmp = smap2(layer_albedo, weight, [](float a, float w) { return w == 0.f ? 0.f : a / w; });
     return max_comp(tmp);
 }
-inline float3 layering_weight(float3 layer_albedo, float3 weight) {
+inline Spec layering_weight(Spec layer_albedo, Spec weight) {
     return weight * saturate_(1.f - layering_weight_max(layer_albedo, weight));
 }
 // Material::compute_shading_frame (material.cpp:331-353) with detail::clamp_ns (:305-310) and PartialDerivative::update(n, s)
@@ -1043,7 +1058,7 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
             break;
         }
         case VMK_MAT_METAL: { // metal.cpp:137-156
-            l.kind = LB_MICROFACET; l.kr = make_float3(1.f);
+            l.kind = LB_MICROFACET; l.kr = make_spec(1.f);
             microfacet_alpha(s, m, 2, 3, it.uv, 0.0001f, &l.ax, &l.ay);
             l.fr.kind = FR_CONDUCTOR; l.fr.a = eval_slot_spd(s, m.slot[0], it.uv); l.fr.b = eval_slot_spd(s, m.slot[1], it.uv);
             l.compensate = true; l.bxdf_flags = flag::GlossyRefl;
@@ -1052,7 +1067,7 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
         case VMK_MAT_PLASTIC: { // plastic.cpp:103-122 (same double roughness_to_alpha as substrate)
             l.kind = LB_PLASTIC;
             l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
-            float3 Rs = eval_slot_albedo(s, m.slot[1], it.uv);
+            Spec Rs = eval_slot_albedo(s, m.slot[1], it.uv);
             float ior = eval_slot1(s, m.slot[2], it.uv);
             float ax, ay; microfacet_alpha(s, m, 3, 4, it.uv, 0.0001f, &ax, &ay);
             if (m.flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
@@ -1072,8 +1087,8 @@ inline void build_simple_lobe(const vmk_scene *s, const vmk_material &m, const I
             l.kind = LB_DIELECTRIC; l.kr = eval_slot_albedo(s, m.slot[0], it.uv);
             float cos_t = dot(it.wo, it.ng); // Interaction::correct_eta interaction.cpp:80-83
             if (m.slot[1].tex == VMK_SLOT_SPD) { // hero, dispersive: one ior per wavelength, directions follow eta[0] (lobe.cpp:353,383,407)
-                float3 iors = eval_slot_spd(s, m.slot[1], it.uv);
-                iors = cos_t > 0.f ? iors : make_float3(rcp(iors.x), rcp(iors.y), rcp(iors.z));
+                Spec iors = eval_slot_spd(s, m.slot[1], it.uv);
+                iors = cos_t > 0.f ? iors : smap(iors, [](float v) { return rcp(v); });
                 microfacet_alpha(s, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay);
                 l.fr.kind = FR_DIELECTRIC; l.fr.eta = iors.x; l.fr.a = iors; l.fr.eta_sp = true;
                 break;
@@ -1100,19 +1115,19 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
     Interaction it = it_in; it.shading = compute_shading_frame(s, m, it_in); // :353 — every lobe below takes it.shading as its frame
     out.is_set = true; out.n = 0;
     float2 uv = it.uv;
-    float3 color = eval_slot_albedo(s, m.slot[VMK_P_COLOR], uv);
+    Spec color = eval_slot_albedo(s, m.slot[VMK_P_COLOR], uv);
     float ior = eval_slot1(s, m.slot[VMK_P_IOR], uv);
     float roughness = clamp_(eval_slot1(s, m.slot[VMK_P_ROUGHNESS], uv), 0.0001f, 1.f);
     float anisotropic = eval_slot1(s, m.slot[VMK_P_ANISOTROPIC], uv);
-    float3 specular_tint = eval_slot_albedo(s, m.slot[VMK_P_SPEC_TINT], uv);
+    Spec specular_tint = eval_slot_albedo(s, m.slot[VMK_P_SPEC_TINT], uv);
     float aspect = sqrtf(1.f - anisotropic * 0.9f);
     float ax = fmax_(0.001f, sqr(roughness) / aspect), ay = fmax_(0.001f, sqr(roughness) * aspect);
-    float3 weight = make_float3(1.f);
+    Spec weight = make_spec(1.f);
     float cos_t = dot(it.wo, it.ng);
     float front_factor = cos_t > 0.f ? 1.f : 0.f;
     auto push = [&](const Lobe &l) { out.lobes[out.n++] = l; };
     if (s->luts.sheen_approx) { // sheen (Approximate mode default, principled_bsdf.cpp:260)
-        float3 sheen_tint = eval_slot_albedo(s, m.slot[VMK_P_SHEEN_TINT], uv);
+        Spec sheen_tint = eval_slot_albedo(s, m.slot[VMK_P_SHEEN_TINT], uv);
         float sheen_weight = eval_slot1(s, m.slot[VMK_P_SHEEN_WEIGHT], uv) * front_factor;
         float sheen_roughness = eval_slot1(s, m.slot[VMK_P_SHEEN_ROUGHNESS], uv);
         Lobe l; l.kind = LB_SHEEN; l.frame = it.shading;
@@ -1121,7 +1136,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
         l.kr = (sheen_tint * sheen_weight * weight) * c[2];
         l.bxdf_flags = flag::GlossyRefl;
         l.sample_weight = average(l.kr); l.weight = 1.f;
-        float3 albedo = l.kr;
+        Spec albedo = l.kr;
         push(l);
         weight = layering_weight(albedo, weight);
     }
@@ -1130,7 +1145,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
         float cc_roughness = clamp_(eval_slot1(s, m.slot[VMK_P_COAT_ROUGHNESS], uv), 0.0001f, 1.f);
         cc_roughness = sqr(cc_roughness);
         float cc_ior = eval_slot1(s, m.slot[VMK_P_COAT_IOR], uv);
-        float3 cc_tint = eval_slot_albedo(s, m.slot[VMK_P_COAT_TINT], uv);
+        Spec cc_tint = eval_slot_albedo(s, m.slot[VMK_P_COAT_TINT], uv);
         Lobe l; l.kind = LB_MICROFACET; l.frame = it.shading; l.ax = l.ay = cc_roughness;
         l.fr.kind = FR_DIELECTRIC; l.fr.eta = cc_ior;
         l.kr = (weight * cc_weight) * cc_tint;
@@ -1138,7 +1153,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
         float x = sqrtf(sqrtf(l.ax * l.ay)); // MicrofacetLobe::to_ratio_x lobe.cpp:187-192
         float z = inverse_lerp(cc_ior, 1.003f, 4.f);
         float sv; sample_lut3d(s->luts.coat, 1, make_float3(x, cos_t, z), &sv);
-        float3 albedo = l.kr * sv;
+        Spec albedo = l.kr * sv;
         l.sample_weight = average(albedo); l.weight = 1.f;
         l.albedo_lut = 1; l.lut_x = x; l.lut_z = z;
         weight = layering_weight(albedo, weight);
@@ -1156,7 +1171,7 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
     { // transmission
         float trans_weight = eval_slot1(s, m.slot[VMK_P_TRANS_WEIGHT], uv);
         float eta = cos_t > 0.f ? ior : rcp(ior);
-        float3 t_weight = weight * trans_weight;
+        Spec t_weight = weight * trans_weight;
         Lobe l; l.kind = LB_DIELECTRIC; l.frame = it.shading; l.ax = ax; l.ay = ay;
         l.fr.kind = FR_SCHLICK; l.fr.a = specular_tint * schlick_F0_from_ior(eta); l.fr.eta = eta;
         l.kr = color;
@@ -1172,14 +1187,14 @@ inline void build_principled(const vmk_scene *s, const vmk_material &m, const In
         float x = sqrtf(sqrtf(ax * ay));
         float z = sqrtf(abs_((ior - 1.0f) / (ior + 1.0f))); // ior_to_ratio_z lobe.h:174-176
         float sv; sample_lut3d(s->luts.specular, 1, make_float3(x, cos_t, z), &sv);
-        float3 albedo = lerp3(sv, l.fr.a, make_float3(1.f)) * l.kr;
+        Spec albedo = lerp3(sv, l.fr.a, make_spec(1.f)) * l.kr;
         l.sample_weight = average(albedo); l.weight = 1.f;
         l.albedo_lut = 2; l.lut_x = x; l.lut_z = z;
         push(l);
         weight = layering_weight(albedo, weight);
     }
     { // diffuse
-        float3 diff_weight = color * weight * front_factor;
+        Spec diff_weight = color * weight * front_factor;
         Lobe l; l.kind = LB_LAMBERT; l.frame = it.shading; l.kr = diff_weight; l.bxdf_flags = flag::DiffRefl;
         l.sample_weight = average(diff_weight); l.weight = 1.f;
         push(l);
@@ -1219,7 +1234,7 @@ inline void build_lobe_set(const vmk_scene *s, const vmk_material &m, const Inte
 // a7-a10. lights — base/illumination/lightsampler.cpp, render_core/light/area.cpp, environments/spherical.cpp,
 //                 render_core/warper/alias.h, alias2d.cpp
 // =====================================================================================================
-struct LightEval { float3 L{0, 0, 0}; float pdf{0.f}; };
+struct LightEval { Spec L = make_spec(0.f); float pdf{0.f}; };
 struct LightSample { LightEval eval; float3 p_light{0, 0, 0}; bool valid() const { return eval.pdf > 0.f; } };
 struct LightSampleContext { float3 pos, ng; };
 
@@ -1281,8 +1296,8 @@ inline void light_select(const LightCtx &c, float u, uint32_t *index, float *pmf
     *index = light_select_inner(c, u);
     *pmf = light_pmf_inner(c, *index);
 }
-inline float3 area_L(const vmk_scene *s, const vmk_light &l, float2 uv, float3 ng, float3 w) { // area.cpp:91-95
-    float3 radiance = eval_slot_illumination(s, l.color, uv) * l.scale;
+inline Spec area_L(const vmk_scene *s, const vmk_light &l, float2 uv, float3 ng, float3 w) { // area.cpp:91-95
+    Spec radiance = eval_slot_illumination(s, l.color, uv) * l.scale;
     return radiance * ((dot(w, ng) > 0.f || l.two_sided) ? 1.f : 0.f);
 }
 inline float area_PDF_wi(float pdf_pos, float3 ng, float3 w) { // area.cpp:114-118
@@ -1306,7 +1321,7 @@ inline LightSample area_sample_wi(const LightCtx &c, const vmk_light &l, const L
     ret.p_light = robust_pos(it.pos, it.ng, w, c.p->ray_offset_factor);
     return ret;
 }
-inline float3 env_L(const vmk_scene *s, const vmk_light &l, float3 local_dir) { // spherical.cpp:60-68
+inline Spec env_L(const vmk_scene *s, const vmk_light &l, float3 local_dir) { // spherical.cpp:60-68
     float2 uv = {spherical_phi(local_dir) * Inv2Pi, spherical_theta(local_dir) * InvPi};
     return eval_slot_illumination(s, l.color, uv) * l.scale;
 }
@@ -1359,7 +1374,7 @@ inline LightSample point_sample_wi(const vmk_scene *s, const vmk_light &l, const
     LightSample ls;
     float3 pos = ld3(l.position);
     float3 w_un = p_ref.pos - pos;
-    float3 value = eval_slot_illumination(s, l.color, make_float2(0.f, 0.f)) * l.scale;
+    Spec value = eval_slot_illumination(s, l.color, make_float2(0.f, 0.f)) * l.scale;
     if (l.type == VMK_LIGHT_SPOT) {
         float3 w = normalize(w_un);
         float cos_theta = clamp_(dot(ld3(l.direction), w), l.cos_angle, l.cos_falloff_start);
@@ -1454,16 +1469,16 @@ inline Ray generate_ray(const vmk_render_params &p, uint32_t px, uint32_t py, Sa
 //        linear depth (sensor.cpp:192-195), MaterialEvaluator::albedo (material.cpp:91-98) = LobeSet::albedo
 //        (lobe.cpp:564-570) over the per-class Lobe::albedo, emission via evaluate_hit_wi
 // =====================================================================================================
-inline float3 lobe_albedo(const vmk_scene *s, const Lobe &l, float cos_theta) {
+inline Spec lobe_albedo(const vmk_scene *s, const Lobe &l, float cos_theta) {
     switch (l.kind) {
         case LB_LAMBERT: case LB_OREN_NAYAR: case LB_FRESNEL_BLEND: return l.kr; // bxdf.h:91,153; substrate.cpp:22
         case LB_MICROFACET: {
             if (l.albedo_lut == 1) { float sv; sample_lut3d(s->luts.coat, 1, make_float3(l.lut_x, cos_theta, l.lut_z), &sv); return sv * l.kr; }
-            if (l.albedo_lut == 2) { float sv; sample_lut3d(s->luts.specular, 1, make_float3(l.lut_x, cos_theta, l.lut_z), &sv); return lerp3(sv, l.fr.a, make_float3(1.f)) * l.kr; }
+            if (l.albedo_lut == 2) { float sv; sample_lut3d(s->luts.specular, 1, make_float3(l.lut_x, cos_theta, l.lut_z), &sv); return lerp3(sv, l.fr.a, make_spec(1.f)) * l.kr; }
             return l.kr * l.fr.evaluate(cos_theta); // MicrofacetLobe::albedo lobe.cpp:208-210
         }
         case LB_PLASTIC: return l.fr.evaluate(cos_theta); // MicrofacetLobe::albedo with the specular bxdf's kr = 1 (plastic.cpp:119)
-        case LB_DIELECTRIC: { float3 F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; } // lobe.cpp:308-313
+        case LB_DIELECTRIC: { Spec F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; } // lobe.cpp:308-313
         default: return l.kr; // sheen: its directional albedo is folded into kr at build time (principled_bsdf.cpp:54-57)
     }
 }
@@ -1489,13 +1504,14 @@ inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const flo
     if (it.has_material()) {
         LobeSet lobes; build_lobe_set(s, s->materials[it.mat_id], it, lobes);
         float cos_theta = dot(it.shading.z, it.wo);
-        if (!lobes.is_set) a.albedo = lobe_albedo(s, lobes.lobes[0], cos_theta);
-        else for (int i = 0; i < lobes.n; ++i) a.albedo += lobe_albedo(s, lobes.lobes[i], cos_theta) * lobes.lobes[i].weight;
+        // (the G-buffer pass exists for spectrum/srgb only, like the device's: the spectrum is the RGB triple)
+        if (!lobes.is_set) a.albedo = spec_as_rgb(lobe_albedo(s, lobes.lobes[0], cos_theta));
+        else for (int i = 0; i < lobes.n; ++i) a.albedo += spec_as_rgb(lobe_albedo(s, lobes.lobes[i], cos_theta) * lobes.lobes[i].weight);
     }
     if (it.has_emission()) {
         LightCtx lc{s, &p};
         LightSampleContext p_ref{ray.o, ray.d};
-        a.emission = light_evaluate_hit_wi(lc, p_ref, it).L;
+        a.emission = spec_as_rgb(light_evaluate_hit_wi(lc, p_ref, it).L);
     }
     return a;
 }
@@ -1505,15 +1521,15 @@ inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const flo
 //        base/scattering/interaction.h:136-139, interaction.cpp:12-32,114-134, geometry.cpp:187-199
 // =====================================================================================================
 // sigma_t / sigma_s as spectra: decode_to_unbound_spectrum of the RGB coefficients (homogeneous.cpp:30-31,34,54-55)
-inline float3 medium_sigma_t(const vmk_scene *s, const vmk_medium &m) { return spec_unbound(s, (ld3(m.sigma_a) + ld3(m.sigma_s)) * m.scale); }
-inline float3 medium_sigma_s(const vmk_scene *s, const vmk_medium &m) { return spec_unbound(s, ld3(m.sigma_s) * m.scale); }
-inline float3 exp3(float3 v) { return make_float3(exp_(v.x), exp_(v.y), exp_(v.z)); }
-inline float3 medium_Tr(const vmk_scene *s, const vmk_medium &m, float t) { return exp3((-1.f * medium_sigma_t(s, m)) * fmin_(RayTMax, t)); } // :33-36
-inline float3 medium_Tr_ray(const vmk_scene *s, const vmk_medium &m, const Ray &r) { return medium_Tr(s, m, length(r.d) * r.t_max); }        // :45-48
+inline Spec medium_sigma_t(const vmk_scene *s, const vmk_medium &m) { return spec_unbound(s, (ld3(m.sigma_a) + ld3(m.sigma_s)) * m.scale); }
+inline Spec medium_sigma_s(const vmk_scene *s, const vmk_medium &m) { return spec_unbound(s, ld3(m.sigma_s) * m.scale); }
+inline Spec exp3(Spec v) { return smap(v, [](float x) { return exp_(x); }); }
+inline Spec medium_Tr(const vmk_scene *s, const vmk_medium &m, float t) { return exp3((-1.f * medium_sigma_t(s, m)) * fmin_(RayTMax, t)); } // :33-36
+inline Spec medium_Tr_ray(const vmk_scene *s, const vmk_medium &m, const Ray &r) { return medium_Tr(s, m, length(r.d) * r.t_max); }        // :45-48
 // Geometry::Tr geometry.cpp:187-199
-inline float3 geometry_Tr(const vmk_scene *s, const vmk_render_params &p, const Ray &r, uint32_t medium) {
+inline Spec geometry_Tr(const vmk_scene *s, const vmk_render_params &p, const Ray &r, uint32_t medium) {
     if (p.process_mediums && medium != VMK_INVALID) return medium_Tr_ray(s, s->mediums[medium], r);
-    return make_float3(1.f);
+    return make_spec(1.f);
 }
 // the medium a ray spawned at `it` towards dir travels in — Interaction::spawn_ray_state interaction.cpp:114-123
 inline uint32_t spawn_medium(const vmk_render_params &p, const Interaction &it, float3 dir) {
@@ -1525,10 +1541,10 @@ inline float phase_HG(float cos_theta, float g) { // interaction.h:136-139
     return Inv4Pi * (1.f - sqr(g)) / (denom * sqrtf(denom));
 }
 // HomogeneousMedium::sample homogeneous.cpp:50-70 (2 draws); may replace `it` by a medium interaction
-inline float3 medium_sample(const vmk_scene *s, const vmk_medium &m, uint32_t medium_id, const Ray &ray, Interaction &it, Sampler &sampler) {
-    float3 sigma_t = medium_sigma_t(s, m), sigma_s = medium_sigma_s(s, m);
-    uint32_t channel = (uint32_t) (sampler.next_1d() * 3.f); if (channel > 2u) channel = 2u;
-    float st_c = channel == 0 ? sigma_t.x : (channel == 1 ? sigma_t.y : sigma_t.z);
+inline Spec medium_sample(const vmk_scene *s, const vmk_medium &m, uint32_t medium_id, const Ray &ray, Interaction &it, Sampler &sampler) {
+    Spec sigma_t = medium_sigma_t(s, m), sigma_s = medium_sigma_s(s, m);
+    uint32_t channel = (uint32_t) (sampler.next_1d() * (float) kSpecDim); if (channel > kSpecDim - 1u) channel = kSpecDim - 1u; // min(uint(u * dimension), dimension - 1)
+    float st_c = scomp(sigma_t, channel);
     float dist = -log_(1.f - sampler.next_1d()) / st_c;
     float t = fmin_(dist / length(ray.d), ray.t_max);
     bool sampled_medium = t < ray.t_max;
@@ -1540,9 +1556,9 @@ inline float3 medium_sample(const vmk_scene *s, const vmk_medium &m, uint32_t me
         mi.med_inside = medium_id; mi.med_outside = medium_id;
         it = mi;
     }
-    float3 tr = medium_Tr(s, m, t);
-    float3 density = sampled_medium ? sigma_t * tr : tr;
-    float pdf = (density.x + density.y + density.z) / 3.f;
+    Spec tr = medium_Tr(s, m, t);
+    Spec density = sampled_medium ? sigma_t * tr : tr;
+    float pdf = average(density);
     return sampled_medium ? tr * sigma_s / pdf : tr / pdf;
 }
 // HenyeyGreenstein::sample interaction.cpp:16-32 (2 draws)
@@ -1574,7 +1590,8 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
     const vmk_scene *s = sv.s;
     tl_swl = swl;
     LightCtx lc{s, &p};
-    float3 L = make_float3(0.f), T = make_float3(1.f);
+    float3 L = make_float3(0.f);
+    Spec T = make_spec(1.f);
     float scatter_pdf = 1e16f;
     float eta_scale = 1.f;
     float3 prev_surface_ng = ray.d;
@@ -1596,7 +1613,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         if (hit.is_miss()) { // evaluate_miss :137-158
             if (s->env_light != VMK_INVALID) {
                 LightSampleContext p_ref{ray.o, prev_surface_ng};
-                float3 tr = make_float3(1.f);
+                Spec tr = make_spec(1.f);
                 if (p.process_mediums) { // :146-151: rs.ray.dir_max.w = world_diameter; tr = geometry.Tr(scene, swl, rs)
                     ray.t_max = s->lights[s->env_light].world_diameter;
                     tr = geometry_Tr(s, p, ray, ray_medium);
@@ -1620,7 +1637,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         if (it.has_emission()) { // integrator.cpp:221-231
             LightSampleContext p_ref{ray.o, prev_surface_ng};
             LightEval eval = light_evaluate_hit_wi(lc, p_ref, it);
-            float3 tr = geometry_Tr(s, p, ray, ray_medium);
+            Spec tr = geometry_Tr(s, p, ray, ray_medium);
             float weight = correct_bsdf_weight(MIS_weight(scatter_pdf, eval.pdf), bounces);
             L += spec_linear_srgb(s, eval.L * T * weight * tr);
         }
@@ -1638,22 +1655,22 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         LightSample ls = light_sample_wi(lc, lsc, sampler);
         Ray shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
         bool occluded = sv.trace_occlusion(shadow_ray);
-        float3 tr = geometry_Tr(s, p, shadow_ray, spawn_medium(p, it, shadow_ray.d)); // geometry.cpp:176-185, integrator.cpp:244
+        Spec tr = geometry_Tr(s, p, shadow_ray, spawn_medium(p, it, shadow_ray.d)); // geometry.cpp:176-185, integrator.cpp:244
         // direct_lighting (integrator.cpp:20-37) via direct_light_mis (integrator.h:164-176)
         float3 wi = normalize(ls.p_light - it.pos);
         ScatterEval scatter_eval;
         BSDFSample bs;
         if (it.has_phase()) { // integrator.cpp:271-279: the phase function stands in for the BSDF
             float f = phase_HG(dot(it.wo, wi), it.g);
-            scatter_eval.f = make_float3(f); scatter_eval.pdf = f; scatter_eval.flags = 0;
+            scatter_eval.f = make_spec(f); scatter_eval.pdf = f; scatter_eval.flags = 0;
             float fs;
             bs.wi = hg_sample(it.wo, it.g, sampler, &fs);
-            bs.eval.f = make_float3(fs); bs.eval.pdf = fs; bs.eval.flags = 0;
+            bs.eval.f = make_spec(fs); bs.eval.pdf = fs; bs.eval.flags = 0;
         } else {
             LobeSet lobes;
             build_lobe_set(s, s->materials[it.mat_id], it, lobes);
             // SampledWavelengths::check_dispersive (spectrum.cpp:32-39, integrator.cpp:264): a dispersive lobe keeps the hero wavelength only
-            if (swl && s->materials[it.mat_id].type == VMK_MAT_GLASS && (s->materials[it.mat_id].flags & VMK_MATF_DISPERSIVE)) { swl->pdf[1] = 0.f; swl->pdf[2] = 0.f; }
+            if (swl && s->materials[it.mat_id].type == VMK_MAT_GLASS && (s->materials[it.mat_id].flags & VMK_MATF_DISPERSIVE)) { for (uint32_t i = 1; i < kSpecDim; ++i) swl->pdf[i] = 0.f; } // invalidation_secondary spectrum.cpp:21-30
             scatter_eval = evaluator_evaluate(s, lobes, it.ng, it.wo, wi);
             bs = evaluator_sample(s, lobes, it.ng, it.wo, sampler);
         }
@@ -1662,7 +1679,7 @@ inline float3 Li(SceneView &sv, const vmk_render_params &p, Ray ray, Sampler &sa
         bool mis = p.mis_mode != 1;
         float weight = mis ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, scatter_eval.pdf)) : 1.f;
         ls.eval.pdf = is_delta_light ? -ls.eval.pdf : ls.eval.pdf;
-        float3 Ld = make_float3(0.f);
+        Spec Ld = make_spec(0.f);
         if (!occluded && scatter_eval.valid() && ls.valid()) Ld = ls.eval.L * scatter_eval.f * weight / ls.eval.pdf;
         if (p.mis_mode == 2) Ld = Ld * 0.f;
         L += spec_linear_srgb(s, T * Ld * tr);
@@ -1725,7 +1742,11 @@ struct orc_scene_handle { SceneView sv; };
 
 extern "C" {
 
+uint32_t orc_spec_dim(void) { return kSpecDim; }
 void *orc_scene_create(const vmk_scene *scene) {
+    // each build of this file serves one SampledSpectrum dimension (omath.h): refuse the other one's scenes
+    const uint32_t dim = scene->spectrum == VMK_SPECTRUM_HERO && scene->spectrum_dimension == 4 ? 4u : 3u;
+    if (dim != kSpecDim) { fprintf(stderr, "oracle: scene needs the ORC_SPEC_DIM = %u build, this is %u\n", dim, kSpecDim); return nullptr; }
     init_srgb_lut();
     auto *h = new orc_scene_handle();
     h->sv.s = scene;
@@ -1930,21 +1951,26 @@ int orc_test_eval(void *h, const vmk_render_params *p, uint32_t kind, uint32_t n
                 o[64] = L.x; o[65] = L.y; o[66] = L.z;
                 break;
             }
-            case 60: { // oracle-only, hero scenes: in (r, g, b, u) -> lambda[3], pdf[3], albedo / unbound / illumination spectra, linear_srgb of each
+            case 60: { // oracle-only, hero scenes: in (r, g, b, u) -> lambda[N], pdf[N], albedo / unbound / illumination spectra [N each], linear_srgb of each [3 each]; N = kSpecDim
                 if (!sv || !is_hero(sv->s)) return -1;
                 Sampler smp; smp.state = 0;
                 Swl swl;
-                for (uint32_t k = 0; k < 3u; ++k) { // sample_wavelength with the draw replaced by the given u (hero.cpp:286-299)
-                    float up = fract_(a[3] + (float) k * (1.f / 3.f));
+                for (uint32_t k = 0; k < kSpecDim; ++k) { // sample_wavelength with the draw replaced by the given u (hero.cpp:286-299)
+                    float up = fract_(a[3] + (float) k * (1.f / (float) kSpecDim));
                     swl.lambda[k] = sample_visible_wavelength(up); swl.pdf[k] = visible_wavelength_PDF(swl.lambda[k]);
                 }
                 tl_swl = &swl;
                 float3 rgb = make_float3(a[0], a[1], a[2]);
-                float3 al = spec_albedo(sv->s, rgb), un = spec_unbound(sv->s, rgb), il = spec_illumination(sv->s, rgb);
+                Spec al = spec_albedo(sv->s, rgb), un = spec_unbound(sv->s, rgb), il = spec_illumination(sv->s, rgb);
                 float3 ral = spec_linear_srgb(sv->s, al), run = spec_linear_srgb(sv->s, un), ril = spec_linear_srgb(sv->s, il);
-                float v[24] = {swl.lambda[0], swl.lambda[1], swl.lambda[2], swl.pdf[0], swl.pdf[1], swl.pdf[2], al.x, al.y, al.z, un.x, un.y, un.z,
-                               il.x, il.y, il.z, ral.x, ral.y, ral.z, run.x, run.y, run.z, ril.x, ril.y, ril.z};
-                for (int k = 0; k < 24; ++k) o[k] = v[k];
+                float *q = o;
+                for (uint32_t k = 0; k < kSpecDim; ++k) *q++ = swl.lambda[k];
+                for (uint32_t k = 0; k < kSpecDim; ++k) *q++ = swl.pdf[k];
+                for (uint32_t k = 0; k < kSpecDim; ++k) *q++ = scomp(al, k);
+                for (uint32_t k = 0; k < kSpecDim; ++k) *q++ = scomp(un, k);
+                for (uint32_t k = 0; k < kSpecDim; ++k) *q++ = scomp(il, k);
+                const float v[9] = {ral.x, ral.y, ral.z, run.x, run.y, run.z, ril.x, ril.y, ril.z};
+                for (int k = 0; k < 9; ++k) *q++ = v[k];
                 tl_swl = nullptr;
                 break;
             }
@@ -1976,11 +2002,11 @@ int orc_integrate_albedo(uint32_t which, uint32_t res, uint32_t x, uint32_t y, u
     float cos_t = clamp_(ry, 1e-4f, 1.0f); // from_ratio_y lobe.cpp:158-164
     float3 wo = make_float3(sqrtf(1.f - sqr(cos_t)), 0.f, cos_t);
     switch (which) {
-        case 0: l.kind = LB_MICROFACET; l.fr.kind = FR_CONSTANT; l.kr = make_float3(1.f); break;
-        case 1: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 5.f); l.kr = make_float3(1.f); break;
-        case 2: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = rcp(lerp_(rz, 1.003f, 5.f)); l.kr = make_float3(1.f); break;
-        case 3: l.kind = LB_MICROFACET; l.fr.kind = FR_SCHLICK; l.fr.a = make_float3(0.04f); l.fr.eta = schlick_ior_from_F0(pow4(rz)); l.kr = make_float3(1.f); break;
-        case 4: l.kind = LB_MICROFACET; l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 4.f); l.kr = make_float3(1.f); break;
+        case 0: l.kind = LB_MICROFACET; l.fr.kind = FR_CONSTANT; l.kr = make_spec(1.f); break;
+        case 1: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 5.f); l.kr = make_spec(1.f); break;
+        case 2: l.kind = LB_DIELECTRIC; l.fr.kind = FR_DIELECTRIC; l.fr.eta = rcp(lerp_(rz, 1.003f, 5.f)); l.kr = make_spec(1.f); break;
+        case 3: l.kind = LB_MICROFACET; l.fr.kind = FR_SCHLICK; l.fr.a = make_spec(0.04f); l.fr.eta = schlick_ior_from_F0(pow4(rz)); l.kr = make_spec(1.f); break;
+        case 4: l.kind = LB_MICROFACET; l.fr.kind = FR_DIELECTRIC; l.fr.eta = lerp_(rz, 1.003f, 4.f); l.kr = make_spec(1.f); break;
         default: return -1;
     }
     double acc0 = 0.0, acc1 = 0.0;
@@ -1994,7 +2020,7 @@ int orc_integrate_albedo(uint32_t which, uint32_t res, uint32_t x, uint32_t y, u
             bool refl = same_hemisphere(wo, sd.wi);
             float eta = l.fr.eta, eta_p = refl ? 1.f : eta;
             float3 wh = face_forward(normalize(wo + sd.wi * eta_p), wo);
-            float3 F = l.fr.evaluate(abs_dot(wh, wo));
+            Spec F = l.fr.evaluate(abs_dot(wh, wo));
             if (refl) { se.f = F * BRDF_div_fr(wo, wh, sd.wi, l.ax, l.ay); se.pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay) * dielectric_refl_prob(l, F); }
             else {
                 float3 wh2 = normalize(wo + sd.wi * eta);

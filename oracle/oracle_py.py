@@ -11,26 +11,30 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_DIR)
-_SO = os.path.join(_DIR, "_build", "liboracle.so")
-_LIB = None
+_SO = {3: os.path.join(_DIR, "_build", "liboracle.so"), 4: os.path.join(_DIR, "_build", "liboracle4.so")}
+_LIB = {}
 
 
 def build(force=False):
+    """Two builds of the same source: SampledSpectrum of 3 values (spectrum/srgb, spectrum/hero dimension 3) and of 4
+    (spectrum/hero with "dimension": 4) — omath.h ORC_SPEC_DIM."""
     src = [os.path.join(_DIR, "oracle.cpp"), os.path.join(_DIR, "omath.h"), os.path.join(_ROOT, "include", "vmk.h")]
-    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src):
-        return _SO
-    os.makedirs(os.path.dirname(_SO), exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", _SO, src[0], "-lpthread"]
-    subprocess.check_call(cmd)
-    return _SO
+    for dim, so in _SO.items():
+        if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in src):
+            continue
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", f"-DORC_SPEC_DIM={dim}", "-o", so, src[0], "-lpthread"]
+        subprocess.check_call(cmd)
+    return _SO[3]
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(_SO):
+def lib(dim=3):
+    if dim not in _LIB:
+        if not os.path.exists(_SO[dim]):
             build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(_SO[dim])
+        L.orc_spec_dim.restype = C.c_uint32
+        assert L.orc_spec_dim() == dim
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.c_void_p]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
@@ -45,8 +49,8 @@ def lib():
         L.orc_render_aov.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_dump_rays.restype = C.c_uint32
         L.orc_dump_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
-        _LIB = L
-    return _LIB
+        _LIB[dim] = L
+    return _LIB[dim]
 
 
 def _ptr(a):
@@ -58,7 +62,11 @@ class OracleScene:
 
     def __init__(self, host_scene):
         self.host_scene = host_scene
-        self._h = lib().orc_scene_create(C.cast(host_scene.tables, C.c_void_p))
+        sc = host_scene.scene
+        self.dim = 4 if (sc.spectrum == 1 and sc.spectrum_dimension == 4) else 3
+        self._L = lib(self.dim)
+        self._h = self._L.orc_scene_create(C.cast(host_scene.tables, C.c_void_p))
+        assert self._h, "oracle refused the scene"
 
     def render(self, params, frame_begin, frame_count, accum=None, tiles=None, threads=0):
         from vision_amd import _abi
@@ -66,8 +74,8 @@ class OracleScene:
         if accum is None:
             accum = np.zeros((h, w, 4), dtype=np.float32)
         cnt = _abi.Counters()
-        lib().orc_reset_counters(self._h)
-        lib().orc_render(self._h, C.byref(params), frame_begin, frame_count, C.byref(tiles) if tiles else None,
+        self._L.orc_reset_counters(self._h)
+        self._L.orc_render(self._h, C.byref(params), frame_begin, frame_count, C.byref(tiles) if tiles else None,
                          _ptr(accum), threads, C.byref(cnt))
         return accum, cnt.as_dict()
 
@@ -77,7 +85,7 @@ class OracleScene:
         dirs = np.ascontiguousarray(dirs, np.float32)
         tmax = np.ascontiguousarray(tmax, np.float32)
         out = np.zeros((n, 4), np.uint32)
-        lib().orc_trace_rays(self._h, n, _ptr(org), _ptr(dirs), _ptr(tmax), int(any_hit), _ptr(out))
+        self._L.orc_trace_rays(self._h, n, _ptr(org), _ptr(dirs), _ptr(tmax), int(any_hit), _ptr(out))
         return out
 
     def render_aov(self, params, frame=0):
@@ -90,16 +98,16 @@ class OracleScene:
         s2r = np.ascontiguousarray(np.linalg.inv(r2s).T.astype(np.float32)).reshape(-1)
         out["depth"] = np.zeros((h, w), np.float32)
         out["motion"] = np.zeros((h, w, 2), np.float32)
-        lib().orc_render_aov(self._h, C.byref(params), _ptr(w2c), _ptr(s2r), frame, _ptr(out["normal"]), _ptr(out["albedo"]), _ptr(out["emission"]),
+        self._L.orc_render_aov(self._h, C.byref(params), _ptr(w2c), _ptr(s2r), frame, _ptr(out["normal"]), _ptr(out["albedo"]), _ptr(out["emission"]),
                              _ptr(out["depth"]), _ptr(out["motion"]))
         return out
 
     def dump_rays(self, params, frame=0, stride=1):
         """Every ray Li() traces for frame `frame` of each stride-th pixel: dict of SoA arrays (org, dir, tmax, kind,
         path, seq) in path order — the input of the traversal-only replay."""
-        n = lib().orc_dump_rays(self._h, C.byref(params), frame, stride, None, 0)
+        n = self._L.orc_dump_rays(self._h, C.byref(params), frame, stride, None, 0)
         buf = np.zeros((n, 10), np.uint32)
-        lib().orc_dump_rays(self._h, C.byref(params), frame, stride, _ptr(buf), n)
+        self._L.orc_dump_rays(self._h, C.byref(params), frame, stride, _ptr(buf), n)
         f = buf.view(np.float32)
         return {"org": f[:, 0:3].copy(), "dir": f[:, 3:6].copy(), "tmax": f[:, 6].copy(), "kind": buf[:, 7].copy(),
                 "path": buf[:, 8].copy(), "seq": buf[:, 9].copy()}
@@ -107,14 +115,14 @@ class OracleScene:
     def test_eval(self, params, kind, inp, out_stride):
         inp = np.ascontiguousarray(inp, np.float32)
         out = np.zeros((inp.shape[0], out_stride), np.float32)
-        rc = lib().orc_test_eval(self._h, C.byref(params) if params is not None else None, kind, inp.shape[0], _ptr(inp),
+        rc = self._L.orc_test_eval(self._h, C.byref(params) if params is not None else None, kind, inp.shape[0], _ptr(inp),
                                  inp.shape[1], _ptr(out), out_stride)
         assert rc == 0
         return out
 
     def close(self):
         if self._h:
-            lib().orc_scene_destroy(self._h)
+            self._L.orc_scene_destroy(self._h)
             self._h = None
 
     def __del__(self):

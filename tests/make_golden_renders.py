@@ -23,11 +23,17 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          # media; point + spot lights; config 4 "spectral glass"; classroom with its environment map and textures
          ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
          ("cbox_hero_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("cbox_hero_lights", "scenes/cbox/cbox_hero_lights.json", 32, 32, 4),
-         ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2), ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2)]
-MEDIA = {"cbox_media", "classroom_fog", "cbox_hero_media"}  # rendered with the scene's "mediums" block honoured
-HERO = {"glass_of_water_hero", "classroom_hero"}           # shipped scenes with the spectrum forced to hero (vmk_host_options.spectrum)
+         ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2), ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2),
+         # spectrum/hero with "dimension": 4 (cbox-prism.json:692-697): four wavelengths per path — the vmk_hero4.hip instance / the ORC_SPEC_DIM = 4 oracle build
+         ("cbox_hero4", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero4_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
+         ("cbox_hero4_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("glass_of_water_hero4", "scenes/glass-of-water/vision_scene.json", 48, 48, 2)]
+MEDIA = {"cbox_media", "classroom_fog", "cbox_hero_media", "cbox_hero4_media"}  # rendered with the scene's "mediums" block honoured
+SPECTRUM = {"glass_of_water_hero": "hero", "classroom_hero": "hero",  # shipped scenes with the spectrum forced to hero (vmk_host_options.spectrum)
+            "cbox_hero4": "hero4", "cbox_hero4_matte": "hero4", "cbox_hero4_media": "hero4", "glass_of_water_hero4": "hero4"}  # ... to hero with four wavelengths
+ONLY = set(sys.argv[1:])  # optional: regenerate the named cases only
 for name, path, w, h, spp in CASES:
-    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA, spectrum="hero" if name in HERO else None)
+    if ONLY and name not in ONLY: continue
+    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA, spectrum=SPECTRUM.get(name))
     img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
     out = os.path.join(ROOT, "tests", "golden", f"{name}_{w}x{h}x{spp}.npy")
     np.save(out, img)

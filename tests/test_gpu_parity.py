@@ -114,12 +114,17 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("cbox_hero_lights", "scenes/cbox/cbox_hero_lights.json", 32, 32, 4),  # point + spot illumination spectra
     ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),  # config 4 as worded: "spectral glass"
     ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2),            # environment map + image textures through the uplift
+    # spectrum/hero, "dimension": 4 — the vmk_hero4.hip instance (four wavelengths per path) against the ORC_SPEC_DIM = 4 oracle build
+    ("cbox_hero4", "scenes/cbox/cbox_hero.json", 32, 32, 4),
+    ("cbox_hero4_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
+    ("cbox_hero4_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4),
+    ("glass_of_water_hero4", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     hero = "hero" in name
-    hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog", "cbox_hero_media"),
-                          spectrum="hero" if name in ("glass_of_water_hero", "classroom_hero") else None)
-    assert (hs.scene.spectrum == 1) == hero
+    hs, p, osc, _ = _load(backend, scene, w, h, mediums=name in ("cbox_media", "classroom_fog", "cbox_hero_media", "cbox_hero4_media"),
+                          spectrum="hero4" if "hero4" in name else ("hero" if name in ("glass_of_water_hero", "classroom_hero") else None))
+    assert (hs.scene.spectrum == 1) == hero and hs.scene.spectrum_dimension == (4 if "hero4" in name else 3)
     # the megakernel variant this scene selects agrees with the unit kernel (vmk_self_check); hero scenes have their own
     # instance of the path unit kernel (vmk_hero.hip k_unit_path)
     assert backend.self_check() == w * h

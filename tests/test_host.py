@@ -101,7 +101,7 @@ def test_json_comments_and_defaults(built, tmp_path):
 @pytest.mark.parametrize("mutate, needle", [
     (lambda s: s["materials"].append({"type": "subsurface", "name": "x", "param": {}}), "material type 'subsurface'"),
     (lambda s: s["integrator"].update(type="rt"), "integrator/rt"),
-    (lambda s: s["spectrum"].update(type="hero", param={"dimension": 4}), "dimension != 3"),
+    (lambda s: s["spectrum"].update(type="hero", param={"dimension": 5}), "dimension 5"),
     (lambda s: s["spectrum"].update(type="rgb"), "spectrum/rgb"),
     (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "projector", "param": {}}), "light/projector"),
     (lambda s: s["camera"]["param"].update(filter={"type": "blackman", "param": {"radius": 1}}), "filter/blackman"),
@@ -218,6 +218,44 @@ def test_hero_uplift_round_trip(built):
     o6 = osc.test_eval(hs.params, 60, np.array([[3.0, 2.0, 0.5, 0.3]], np.float32), 24)[0]
     o1 = osc.test_eval(hs.params, 60, np.array([[0.5, 1 / 3, 1 / 12, 0.3]], np.float32), 24)[0]
     assert np.allclose(o6[9:12], 6 * o1[6:9], rtol=1e-5)
+
+
+def test_hero_dimension_4_wavelengths_closed_form_and_round_trip(built, tmp_path):
+    """spectrum/hero with "dimension": 4 (cbox-prism.json:692-697; the 4-wavelength megakernel instance / oracle build).
+    HeroWavelengthSpectrum::sample_wavelength (hero.cpp:286-299) rotates the hero draw by i / dimension and maps it through
+    sample_visible_wavelength (hero.cpp:15-24): lambda_i = 538 - 138.888889 atanh(0.85691062 - 1.82750197 fract(u + i / 4)),
+    pdf_i = 0.0039398042 / cosh^2(0.0072 (lambda_i - 538)) — evaluated here in float64, independent of the oracle's code.
+    The uplift round trip holds with four samples as with three, and the host takes the dimension from the scene file or the option."""
+    import json
+    from oracle import oracle_py
+    path = os.path.join(ROOT, "scenes/cbox/cbox_hero.json")
+    hs = HostScene(path, width=16, height=16, spectrum="hero4")
+    assert hs.scene.spectrum == _abi.SPECTRUM_HERO and hs.scene.spectrum_dimension == 4 and "dimension 4" in hs.description
+    assert HostScene(path, width=16, height=16).scene.spectrum_dimension == 3
+    text = open(path).read()
+    sc = json.loads("\n".join(l for l in text.split("\n") if not l.lstrip().startswith("//")))
+    sc["spectrum"] = {"type": "hero", "param": {"dimension": 4}}
+    import shutil; shutil.copy(os.path.join(ROOT, "scenes/cbox/checker.png"), str(tmp_path))  # texture paths are relative to the scene file
+    alt = os.path.join(str(tmp_path), "dim4.json"); json.dump(sc, open(alt, "w"))
+    from_file = HostScene(alt, width=16, height=16)
+    assert from_file.scene.spectrum_dimension == 4 and from_file.scene.n_tris == hs.scene.n_tris
+    osc = oracle_py.OracleScene(hs)
+    assert osc.dim == 4
+    u = ((np.arange(2048) + 0.5) / 2048).astype(np.float32)
+    rgb = np.array([0.2, 0.6, 0.9], np.float32)
+    o = osc.test_eval(hs.params, 60, np.concatenate([np.tile(rgb, (len(u), 1)), u[:, None]], 1), 29)
+    lam, pdf = o[:, 0:4].astype(np.float64), o[:, 4:8].astype(np.float64)
+    up = (u.astype(np.float64)[:, None] + np.arange(4) / 4.0) % 1.0
+    lam_ref = 538.0 - 138.888889 * np.arctanh(0.85691062 - 1.82750197 * up)
+    # (fract(u + i/4) is taken in float32 by the renderer: 2^-24 in `up` moves lambda by < 3e-5 nm in the body of the domain)
+    assert np.abs(lam - lam_ref).max() < 2e-3, np.abs(lam - lam_ref).max()
+    assert np.allclose(pdf, 0.0039398042 / np.cosh(0.0072 * (lam - 538.0)) ** 2, rtol=2e-5)
+    assert np.all((lam >= 360) & (lam <= 830)) and np.all((o[:, 8:12] >= 0) & (o[:, 8:12] <= 1))
+    back = o[:, 26:29].astype(np.float64).mean(0)  # illumination spectrum (uplift x D65) through the CIE observer, 4-sample estimator
+    assert np.allclose(back, rgb, atol=1.2e-2), back
+    # the three-wavelength build refuses the scene instead of reading four samples as three
+    import ctypes as C
+    assert not oracle_py.lib(3).orc_scene_create(C.cast(hs.tables, C.c_void_p))
 
 
 def test_bathroom2_loads_with_declared_standins(built):

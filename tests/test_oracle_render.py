@@ -29,15 +29,20 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          # lights; config 4 as worded ("spectral glass"); classroom with its environment map and image textures
          ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
          ("cbox_hero_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("cbox_hero_lights", "scenes/cbox/cbox_hero_lights.json", 32, 32, 4),
-         ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2), ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2)]
-MEDIA = {"cbox_media", "classroom_fog", "cbox_hero_media"}
-HERO = {"glass_of_water_hero", "classroom_hero"}  # shipped scenes with the spectrum forced to hero (vmk_host_options.spectrum)
+         ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2), ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2),
+         # spectrum/hero with "dimension": 4 (cbox-prism.json:692-697): four wavelengths per path — the vmk_hero4.hip instance / the ORC_SPEC_DIM = 4 oracle build
+         ("cbox_hero4", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero4_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
+         ("cbox_hero4_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("glass_of_water_hero4", "scenes/glass-of-water/vision_scene.json", 48, 48, 2)]
+MEDIA = {"cbox_media", "classroom_fog", "cbox_hero_media", "cbox_hero4_media"}
+SPECTRUM = {"glass_of_water_hero": "hero", "classroom_hero": "hero",  # shipped scenes with the spectrum forced to hero (vmk_host_options.spectrum)
+            "cbox_hero4": "hero4", "cbox_hero4_matte": "hero4", "cbox_hero4_media": "hero4", "glass_of_water_hero4": "hero4"}  # ... to hero with four wavelengths
 
 
 @pytest.mark.parametrize("name, path, w, h, spp", CASES)
 def test_oracle_matches_committed_golden(built, name, path, w, h, spp):
-    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA, spectrum="hero" if name in HERO else None)
+    hs = HostScene(os.path.join(ROOT, path), width=w, height=h, mediums=name in MEDIA, spectrum=SPECTRUM.get(name))
     assert bool(hs.params.process_mediums) == (name in MEDIA)
+    assert hs.scene.spectrum_dimension == (4 if "hero4" in name else 3)
     assert (hs.scene.spectrum == _abi.SPECTRUM_HERO) == ("hero" in name)
     img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, spp)
     gold = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_{w}x{h}x{spp}.npy"))
@@ -141,14 +146,15 @@ def test_hero_spectrum_converges_to_the_srgb_image(built, scene):
     integrated back through the CIE observer give the image the RGB transport gives — equal for direct light, and equal up
     to metamerism (a few % in the weakest channel) after diffuse interreflection.  512 spp of the same 16x16 film."""
     mean = {}
-    for sp in ("srgb", "hero"):
+    for sp in ("srgb", "hero", "hero4"):
         hs = HostScene(os.path.join(ROOT, scene), width=16, height=16, spectrum=sp)
-        assert hs.scene.spectrum == (_abi.SPECTRUM_HERO if sp == "hero" else _abi.SPECTRUM_SRGB)
+        assert hs.scene.spectrum == (_abi.SPECTRUM_SRGB if sp == "srgb" else _abi.SPECTRUM_HERO)
         img, _ = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, 512)
         assert np.isfinite(img).all()
         mean[sp] = img[..., :3].astype(np.float64).reshape(-1, 3).mean(0)
-    ratio = mean["hero"] / mean["srgb"]
-    assert abs(ratio[0] - 1) < 0.015 and abs(ratio[1] - 1) < 0.015 and abs(ratio[2] - 1) < 0.05, ratio
+    for sp in ("hero", "hero4"):  # three and four wavelengths per path estimate the same integral
+        ratio = mean[sp] / mean["srgb"]
+        assert abs(ratio[0] - 1) < 0.015 and abs(ratio[1] - 1) < 0.015 and abs(ratio[2] - 1) < 0.05, (sp, ratio)
 
 
 def test_tile_ownership_is_a_latin_square_of_tiles(built):

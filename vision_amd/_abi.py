@@ -1,7 +1,7 @@
 """ctypes mirror of include/vmk.h and include/vmk_host.h (plain C structs, no torch types)."""
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SLOT_SPD = 0xFFFFFFFD
 SPECTRUM_SRGB, SPECTRUM_HERO = 0, 1
 RGB2SPEC_RES = 64
@@ -66,7 +66,7 @@ class Scene(C.Structure):
                 ("n_mediums", u32), ("mediums", C.POINTER(Medium)),
                 ("light_alias_offset", u32), ("light_alias_integral", f32),
                 ("spectrum", u32), ("rgb2spec", C.POINTER(f32)), ("spd_data", C.POINTER(f32)), ("n_spd", u32),
-                ("spd_cie", u32 * 4), ("spd_cie_count", u32), ("spd_cie_interval", f32), ("cie_y_integral", f32)]
+                ("spd_cie", u32 * 4), ("spd_cie_count", u32), ("spd_cie_interval", f32), ("cie_y_integral", f32), ("spectrum_dimension", u32)]
 
 
 _T = FILTER_TABLE_SIZE

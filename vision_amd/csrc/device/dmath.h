@@ -170,6 +170,53 @@ VD V3 lerp3(float t, V3 a, V3 b) { return a + (b - a) * t; }
 VD V3 saturate3(V3 a) { return {saturate_(a.x), saturate_(a.y), saturate_(a.z)}; }
 VD V4 lerp4(float t, V4 a, V4 b) { return {a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), a.w + t * (b.w - a.w)}; }
 
+// ---- sampled spectrum ----
+// A SampledSpectrum (base/color/spectrum.h:60-170) of the scene's dimension.  Three values — the (R, G, B) channels of spectrum/srgb,
+// or hero dimension 3 — are a V3: the type and the arithmetic the path code had before the dimension became a build parameter.
+// VMK_SPEC_DIM = 4 (vmk_hero4.hip: spectrum/hero with "dimension": 4, cbox-prism.json:692-697) makes it four samples.  Directions,
+// positions and RGB colours stay V3; only values carried per wavelength are Spec.
+#ifndef VMK_SPEC_DIM
+#define VMK_SPEC_DIM 3
+#endif
+struct S4 { float x, y, z, w; };
+VD S4 operator+(S4 a, S4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+VD S4 operator-(S4 a, S4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+VD S4 operator*(S4 a, S4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+VD S4 operator/(S4 a, S4 b) { return {a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w}; }
+VD S4 operator*(S4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+VD S4 operator*(float s, S4 a) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+VD S4 operator/(S4 a, float s) { return {a.x / s, a.y / s, a.z / s, a.w / s}; }
+VD S4 operator-(float s, S4 a) { return {s - a.x, s - a.y, s - a.z, s - a.w}; }
+VD S4 operator-(S4 a) { return {-a.x, -a.y, -a.z, -a.w}; }
+VD S4 &operator+=(S4 &a, S4 b) { a = a + b; return a; }
+VD S4 &operator*=(S4 &a, S4 b) { a = a * b; return a; }
+VD S4 &operator*=(S4 &a, float s) { a = a * s; return a; }
+VD bool is_zero(S4 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f && a.w == 0.f; }
+VD float max_comp(S4 a) { return fmax_(fmax_(fmax_(a.x, a.y), a.z), a.w); }   // SampledSpectrum::max: a left fold (spectrum.h)
+VD float average(S4 a) { return (a.x + a.y + a.z + a.w) / 4.f; }               // SampledSpectrum::average: sum() / dimension
+VD S4 lerp3(float t, S4 a, S4 b) { return a + (b - a) * t; }
+VD S4 saturate3(S4 a) { return {saturate_(a.x), saturate_(a.y), saturate_(a.z), saturate_(a.w)}; }
+#if VMK_SPEC_DIM == 4
+typedef S4 Spec;
+VD Spec mks(float v) { return {v, v, v, v}; }
+template<class F> VD Spec smap(Spec a, F f) { return {f(a.x), f(a.y), f(a.z), f(a.w)}; }
+template<class F> VD Spec smap2(Spec a, Spec b, F f) { return {f(a.x, b.x), f(a.y, b.y), f(a.z, b.z), f(a.w, b.w)}; }
+VD float scomp(Spec a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : (i == 2 ? a.z : a.w)); }
+VD void sput(Spec &a, uint32_t i, float v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else if (i == 2) a.z = v; else a.w = v; }
+VD float ssum(Spec a) { return a.x + a.y + a.z + a.w; }
+#elif VMK_SPEC_DIM == 3
+typedef V3 Spec;
+VD Spec mks(float v) { return {v, v, v}; }
+template<class F> VD Spec smap(Spec a, F f) { return {f(a.x), f(a.y), f(a.z)}; }
+template<class F> VD Spec smap2(Spec a, Spec b, F f) { return {f(a.x, b.x), f(a.y, b.y), f(a.z, b.z)}; }
+VD float scomp(Spec a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+VD void sput(Spec &a, uint32_t i, float v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
+VD float ssum(Spec a) { return a.x + a.y + a.z; }
+#else
+#error "VMK_SPEC_DIM must be 3 or 4"
+#endif
+constexpr uint32_t kSpecDim = VMK_SPEC_DIM;
+
 // ---- local shading geometry (z-up) ----
 VD float cos_theta(V3 w) { return w.z; }
 VD float abs_cos_theta(V3 w) { return abs_(w.z); }

@@ -5,7 +5,7 @@
 
 // VMK_HERO = 1 compiles the path code for the hero-wavelength spectrum (render_core/spectrum/hero.cpp) in its own
 // translation unit (vmk_hero.hip, namespace vmkd_hero): every colour that enters the path is uplifted to a spectrum
-// sampled at the path's three wavelengths.  With VMK_HERO = 0 (srgb.cpp) the colour helpers below are the identity and
+// sampled at the path's wavelengths (three, or VMK_SPEC_DIM = 4 of them in vmk_hero4.hip).  With VMK_HERO = 0 (srgb.cpp) the colour helpers below are the identity and
 // the SWL_P / SWL_A parameter macros expand to nothing, so the sRGB megakernel is the same code as before.
 #ifndef VMK_HERO
 #define VMK_HERO 0
@@ -163,26 +163,30 @@ VD float eval_slot1(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt) 
 
 // =====================================================================================================
 // a2. spectrum — render_core/spectrum/{srgb,hero}.cpp, base/color/{spd,spectrum}.cpp
-// A SampledSpectrum of dimension 3 is a V3 in both modes: the (R, G, B) channels for srgb, the values at the path's
-// wavelengths (hero, hero + 1/3, hero + 2/3 of the sampling domain) for hero.
+// A SampledSpectrum is a Spec (dmath.h): a V3 for dimension 3 in both modes — the (R, G, B) channels for srgb, the values at the
+// path's wavelengths (hero, hero + 1/3, hero + 2/3 of the sampling domain) for hero — or four values for hero dimension 4.
 // =====================================================================================================
 #if VMK_HERO
-struct Swl { V3 lambda, pdf; }; // SampledWavelengths (spectrum.h:18-56): pdf == 0 marks an invalidated secondary wavelength
+struct Swl { Spec lambda, pdf; }; // SampledWavelengths (spectrum.h:18-56): pdf == 0 marks an invalidated secondary wavelength
 VD float sample_visible_wavelength(float u) { return 538.f - 138.888889f * atanh_(0.85691062f - 1.82750197f * u); } // hero.cpp:15-18
 VD float visible_wavelength_PDF(float lambda) { return 0.0039398042f / sqr(cosh_(0.0072f * (lambda - 538.f))); }     // hero.cpp:21-24
 // HeroWavelengthSpectrum::sample_wavelength (hero.cpp:286-299), 1 draw
 VD Swl sample_wavelengths(Sampler &sampler) {
     Swl swl;
     float u = sampler.next_1d();
-    float l[3], p[3];
+    float l[kSpecDim], p[kSpecDim];
 #pragma unroll
-    for (uint32_t i = 0; i < 3u; ++i) {
-        float offset = (float) i * (1.f / 3.f);
+    for (uint32_t i = 0; i < kSpecDim; ++i) {
+        float offset = (float) i * (1.f / (float) kSpecDim);
         float up = fract_(u + offset);
         l[i] = sample_visible_wavelength(up);
         p[i] = visible_wavelength_PDF(l[i]);
     }
+#if VMK_SPEC_DIM == 4
+    swl.lambda = {l[0], l[1], l[2], l[3]}; swl.pdf = {p[0], p[1], p[2], p[3]};
+#else
     swl.lambda = {l[0], l[1], l[2]}; swl.pdf = {p[0], p[1], p[2]};
+#endif
     return swl;
 }
 // SPD::eval (spd.cpp:79-86)
@@ -193,7 +197,7 @@ VD float spd_eval(const float *f, float interval, float lambda) {
     float l = f[i], r = f[i + 1u];
     return lerp_(fract_(t), l, r);
 }
-VD V3 spd_eval3(const float *f, float interval, const Swl &swl) { return {spd_eval(f, interval, swl.lambda.x), spd_eval(f, interval, swl.lambda.y), spd_eval(f, interval, swl.lambda.z)}; }
+VD Spec spd_eval3(const float *f, float interval, const Swl &swl) { return smap(swl.lambda, [&](float lambda) { return spd_eval(f, interval, lambda); }); }
 // RGBSigmoidPolynomial (hero.cpp:27-49)
 VD float sigmoid_polynomial(V3 c, float lambda) {
     float x = fma_(fma_(c.x, lambda, c.y), lambda, c.z);
@@ -241,17 +245,17 @@ VD V3 rgb2spec_unbound_coeffs(const DScene &S, V3 rgb_in, float *scale_out) {
     *scale_out = scale;
     return rgb2spec_albedo_coeffs(S, scale == 0.f ? mk3(0.f) : rgb / scale);
 }
-VD V3 sigmoid3(V3 c, const Swl &swl) { return {sigmoid_polynomial(c, swl.lambda.x), sigmoid_polynomial(c, swl.lambda.y), sigmoid_polynomial(c, swl.lambda.z)}; }
+VD Spec sigmoid3(V3 c, const Swl &swl) { return smap(swl.lambda, [&](float lambda) { return sigmoid_polynomial(c, lambda); }); }
 #endif
 // decode_to_albedo / decode_to_unbound_spectrum / decode_to_illumination (srgb.cpp:49-57, hero.cpp:331-342)
-VD V3 spec_albedo(const DScene &S, V3 rgb SWL_P) {
+VD Spec spec_albedo(const DScene &S, V3 rgb SWL_P) {
 #if VMK_HERO
     return sigmoid3(rgb2spec_albedo_coeffs(S, rgb), swl);
 #else
     return rgb;
 #endif
 }
-VD V3 spec_unbound(const DScene &S, V3 rgb SWL_P) {
+VD Spec spec_unbound(const DScene &S, V3 rgb SWL_P) {
 #if VMK_HERO
     float scale; V3 c = rgb2spec_unbound_coeffs(S, rgb, &scale);
     return sigmoid3(c, swl) * scale; // RGBUnboundSpectrum::eval hero.cpp:201-203
@@ -259,7 +263,7 @@ VD V3 spec_unbound(const DScene &S, V3 rgb SWL_P) {
     return rgb;
 #endif
 }
-VD V3 spec_illumination(const DScene &S, V3 rgb SWL_P) {
+VD Spec spec_illumination(const DScene &S, V3 rgb SWL_P) {
 #if VMK_HERO
     float scale; V3 c = rgb2spec_unbound_coeffs(S, rgb, &scale);
     return (sigmoid3(c, swl) * scale) * spd_eval3(S.hero.spd_data + S.hero.spd_cie[3], S.hero.spd_cie_interval, swl); // RGBIlluminationSpectrum::eval hero.cpp:219-221
@@ -268,14 +272,16 @@ VD V3 spec_illumination(const DScene &S, V3 rgb SWL_P) {
 #endif
 }
 // Spectrum::linear_srgb (srgb.cpp:46-48; hero.cpp:265-267,281-291 + cie::xyz_to_linear_srgb cie.h:413-420)
-VD V3 spec_linear_srgb(const DScene &S, V3 sp SWL_P) {
+VD V3 spec_linear_srgb(const DScene &S, Spec sp SWL_P) {
 #if VMK_HERO
     const float *X = S.hero.spd_data + S.hero.spd_cie[0], *Y = S.hero.spd_data + S.hero.spd_cie[1], *Z = S.hero.spd_data + S.hero.spd_cie[2];
-    float l[3] = {swl.lambda.x, swl.lambda.y, swl.lambda.z}, p[3] = {swl.pdf.x, swl.pdf.y, swl.pdf.z}, v[3] = {sp.x, sp.y, sp.z};
+    float l[kSpecDim], p[kSpecDim], v[kSpecDim];
+#pragma unroll
+    for (uint32_t i = 0; i < kSpecDim; ++i) { l[i] = scomp(swl.lambda, i); p[i] = scomp(swl.pdf, i); v[i] = scomp(sp, i); }
     V3 sum = mk3(0.f);
     uint32_t valid = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (uint32_t i = 0; i < kSpecDim; ++i) {
         float x = spd_eval(X, S.hero.spd_cie_interval, l[i]) * v[i], y = spd_eval(Y, S.hero.spd_cie_interval, l[i]) * v[i], z = spd_eval(Z, S.hero.spd_cie_interval, l[i]) * v[i];
         sum += V3{p[i] == 0.f ? 0.f : x / p[i], p[i] == 0.f ? 0.f : y / p[i], p[i] == 0.f ? 0.f : z / p[i]};
         valid += p[i] > 0.f ? 1u : 0u;
@@ -290,14 +296,18 @@ VD V3 spec_linear_srgb(const DScene &S, V3 sp SWL_P) {
 #endif
 }
 // a colour slot evaluated to a spectrum: ShaderNodeSlot::eval_albedo_spectrum / eval_illumination_spectrum (shader_node.cpp:317-333)
-VD V3 eval_slot_albedo(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) { return spec_albedo(S, eval_slot3(S, sl, uv, cnt) SWL_A); }
-VD V3 eval_slot_illumination(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) { return spec_illumination(S, eval_slot3(S, sl, uv, cnt) SWL_A); }
+VD Spec eval_slot_albedo(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) { return spec_albedo(S, eval_slot3(S, sl, uv, cnt) SWL_A); }
+VD Spec eval_slot_illumination(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) { return spec_illumination(S, eval_slot3(S, sl, uv, cnt) SWL_A); }
 // a number slot that may be an "spd" node in hero mode (metal eta / k, dispersive glass ior): one value per wavelength
-VD V3 eval_slot_spd(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) {
+VD Spec eval_slot_spd(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt SWL_P) {
 #if VMK_HERO
     if (sl.tex == VMK_SLOT_SPD) return spd_eval3(S.hero.spd_data + f2u(sl.v[0]), sl.v[2], swl); // SPDNode::evaluate spd.cpp:36-39
 #endif
+#if VMK_SPEC_DIM == 4
+    return mks(eval_slot1(S, sl, uv, cnt)); // (a complete spectrum feeds these slots from "spd" nodes, metal.cpp:113-117, glass.cpp:229-233; a plain number is one value)
+#else
     return eval_slot3(S, sl, uv, cnt);
+#endif
 }
 
 // =====================================================================================================
@@ -484,30 +494,30 @@ VD float fresnel_complex(float cos_i, float eta_re, float k) { // optics.h:93-10
 enum : int { FR_CONSTANT = 0, FR_CONDUCTOR, FR_DIELECTRIC, FR_SCHLICK, FR_F82 };
 struct Fresnel {
     int kind;
-    V3 a, b; // conductor eta,k | schlick F0 | F82 F0,B
+    Spec a, b; // conductor eta,k | schlick F0 | F82 F0,B
     float eta;
 #if VMK_HERO
     bool eta_sp; // FresnelDielectric over an "spd" ior (dispersive glass): a = the per-wavelength eta, eta = a.x (fresnel.h:83-91)
 #endif
-    VD V3 evaluate(float cos_t) const {
-        if (kind == FR_CONDUCTOR) return {fresnel_complex(cos_t, a.x, b.x), fresnel_complex(cos_t, a.y, b.y), fresnel_complex(cos_t, a.z, b.z)};
+    VD Spec evaluate(float cos_t) const {
+        if (kind == FR_CONDUCTOR) return smap2(a, b, [&](float e, float k) { return fresnel_complex(cos_t, e, k); });
 #if VMK_HERO
-        if (kind == FR_DIELECTRIC && eta_sp) return {fresnel_dielectric(cos_t, a.x), fresnel_dielectric(cos_t, a.y), fresnel_dielectric(cos_t, a.z)};
+        if (kind == FR_DIELECTRIC && eta_sp) return smap(a, [&](float e) { return fresnel_dielectric(cos_t, e); });
 #endif
-        if (kind == FR_DIELECTRIC) { float f = fresnel_dielectric(cos_t, eta); return {f, f, f}; }
+        if (kind == FR_DIELECTRIC) { float f = fresnel_dielectric(cos_t, eta); return mks(f); }
         if (kind == FR_SCHLICK) { // fresnel.h:60-67
             float F_real = fresnel_dielectric(cos_t, eta);
             float F0_real = schlick_F0_from_ior(eta);
             float t = clamp_(inverse_lerp(F_real, F0_real, 1.f), 0.f, 1.f);
-            return lerp3(t, a, mk3(1.f));
+            return lerp3(t, a, mks(1.f));
         }
         if (kind == FR_F82) { // fresnel.h:123-129
             float mu = saturate_(1.f - cos_t);
             float mu5 = pow5(mu);
-            V3 f_schlick = lerp3(mu5, a, mk3(1.f));
+            Spec f_schlick = lerp3(mu5, a, mks(1.f));
             return saturate3(f_schlick - b * cos_t * mu5 * mu);
         }
-        return {1.f, 1.f, 1.f};
+        return mks(1.f);
     }
 };
 
@@ -520,21 +530,21 @@ namespace flag {
 constexpr uint32_t Unset = 1, Reflection = 2, Transmission = 4, Diffuse = 8, Glossy = 16;
 constexpr uint32_t DiffRefl = Diffuse | Reflection, GlossyRefl = Glossy | Reflection, GlossyTrans = Glossy | Transmission;
 }
-struct ScatterEval { V3 f; float pdf; uint32_t flags; };
+struct ScatterEval { Spec f; float pdf; uint32_t flags; };
 struct BSDFSample { ScatterEval eval; V3 wi; float eta; };
 enum : int { LB_LAMBERT = 0, LB_OREN_NAYAR, LB_MICROFACET, LB_FRESNEL_BLEND, LB_DIELECTRIC, LB_SHEEN, LB_PLASTIC };
 struct Lobe {
     int kind;
-    V3 kr, rs;
+    Spec kr, rs;
     float A, B, ax, ay;
     Fresnel fr;
     bool compensate;
     float weight, sample_weight;
 };
 
-VD float dielectric_refl_prob(const Lobe &l, V3 F) { // lobe.cpp:315-319
-    V3 T = 1.f - F;
-    V3 total = T * l.kr + F;
+VD float dielectric_refl_prob(const Lobe &l, Spec F) { // lobe.cpp:315-319
+    Spec T = 1.f - F;
+    Spec total = T * l.kr + F;
     return average(F) / average(total);
 }
 // The albedo tables the lobe code reads.  The out-of-line lobe routine gets these three pointers instead of the scene view,
@@ -548,19 +558,19 @@ VD float dielectric_lut_x(const LobeLuts &S, const Lobe &l, V3 wo, float eta) { 
     float out[2]; sample_lut3d<2>(lut, mk3(x, y, z), out);
     return out[0];
 }
-VD V3 blend_f_specular(const Lobe &l, V3 wo, V3 wi, V3 wh) { // FresnelBlend::f_specular substrate.cpp:31-37
-    V3 specular = lerp3(schlick_weight(dot(wi, wh)), l.rs, mk3(1.f)) *
+VD Spec blend_f_specular(const Lobe &l, V3 wo, V3 wi, V3 wh) { // FresnelBlend::f_specular substrate.cpp:31-37
+    Spec specular = lerp3(schlick_weight(dot(wi, wh)), l.rs, mks(1.f)) *
                   (bsdf_D(wh, l.ax, l.ay) / (4.f * abs_dot(wi, wh) * fmax_(abs_cos_theta(wi), abs_cos_theta(wo))));
     return specular * (is_zero(wh) ? 0.f : 1.f);
 }
 
 // Lobe::evaluate_local_impl of every lobe class (local frame, before the |cos_i| factor)
 VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float *eta_out) {
-    ScatterEval se; se.f = mk3(0.f); se.pdf = 0.f; se.flags = flag::Unset;
+    ScatterEval se; se.f = mks(0.f); se.pdf = 0.f; se.flags = flag::Unset;
     switch (l.kind) {
         case LB_LAMBERT: case LB_OREN_NAYAR: { // bxdf.cpp:34-46, bxdf.h:92-95, bxdf.cpp:103-121
             bool sh = same_hemisphere(wo, wi);
-            V3 f;
+            Spec f;
             if (l.kind == LB_LAMBERT) f = l.kr * InvPi;
             else {
                 float sin_i = sin_theta(wi), sin_o = sin_theta(wo);
@@ -571,7 +581,7 @@ VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float 
                 float tan_beta = cond ? sin_i / abs_cos_theta(wi) : sin_o / abs_cos_theta(wo);
                 f = l.kr * InvPi * (l.A + l.B * max_cos * sin_alpha * tan_beta);
             }
-            se.f = sh ? f : mk3(0.f);
+            se.f = sh ? f : mks(0.f);
             se.pdf = sh ? cosine_hemisphere_PDF(abs_cos_theta(wi)) : 0.f;
             se.flags = flag::DiffRefl;
             break;
@@ -580,10 +590,10 @@ VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float 
             bool sh = same_hemisphere(wo, wi);
             V3 wh = normalize(wo + wi);
             V3 whf = face_forward(wh, mk3(0, 0, 1));
-            V3 F = l.fr.evaluate(abs_dot(wo, whf));
-            V3 f = (F * BRDF_div_fr(wo, whf, wi, l.ax, l.ay)) * l.kr;
+            Spec F = l.fr.evaluate(abs_dot(wo, whf));
+            Spec f = (F * BRDF_div_fr(wo, whf, wi, l.ax, l.ay)) * l.kr;
             float pdf = PDF_wi_reflection(wo, wh, l.ax, l.ay);
-            se.f = sh ? f : mk3(0.f);
+            se.f = sh ? f : mks(0.f);
             se.pdf = sh ? pdf : 0.f;
             se.flags = flag::GlossyRefl;
             if (l.compensate) {
@@ -596,20 +606,20 @@ VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float 
         case LB_FRESNEL_BLEND: { // substrate.cpp:12-70
             bool sh = same_hemisphere(wo, wi);
             V3 wh = normalize(wi + wo);
-            V3 specular = blend_f_specular(l, wo, wi, wh);
-            V3 diffuse = (28.f / (23.f * Pi)) * l.kr * (mk3(1.f) - l.rs) *
+            Spec specular = blend_f_specular(l, wo, wi, wh);
+            Spec diffuse = (28.f / (23.f * Pi)) * l.kr * (mks(1.f) - l.rs) *
                          (1.f - pow5(1.f - .5f * abs_cos_theta(wi))) * (1.f - pow5(1.f - .5f * abs_cos_theta(wo)));
-            V3 f = specular + diffuse;
+            Spec f = specular + diffuse;
             float fr = l.fr.evaluate(abs_cos_theta(wo)).x;
             float pdf = lerp_(fr, cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
-            se.f = sh ? f : mk3(0.f);
+            se.f = sh ? f : mks(0.f);
             se.pdf = sh ? pdf : 0.f;
             se.flags = flag::Reflection;
             break;
         }
         case LB_PLASTIC: { // PlasticLobe::evaluate_local_impl plastic.cpp:31-43 (no hemisphere test of its own)
             V3 wh = normalize(wo + wi);
-            V3 F = l.fr.evaluate(abs_dot(wh, wo));
+            Spec F = l.fr.evaluate(abs_dot(wh, wo));
             se.f = (l.kr * InvPi) * (1.f - F);
             se.f += BRDF_div_fr(wo, wh, wi, l.ax, l.ay) * F;
             se.pdf = lerp_(average(F), cosine_hemisphere_PDF(abs_cos_theta(wi)), PDF_wi_reflection(wo, wh, l.ax, l.ay));
@@ -623,7 +633,7 @@ VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float 
             if (eta_out) *eta_out = eta_p;
             V3 wh = normalize(wo + wi * eta_p);
             wh = face_forward(wh, wo);
-            V3 F = l.fr.evaluate(abs_dot(wh, wo));
+            Spec F = l.fr.evaluate(abs_dot(wh, wo));
             float lutx = dielectric_lut_x(S, l, wo, eta);
             if (refl) {
                 se.f = F * BRDF_div_fr(wo, wh, wi, l.ax, l.ay);
@@ -633,7 +643,7 @@ VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float 
             } else {
                 V3 new_wh = face_forward(wh, wo);
                 V3 wh2 = normalize(wo + wi * eta);
-                V3 tr = (1.f - F) * BTDF_div_ft(wo, wh2, wi, eta, l.ax, l.ay, true);
+                Spec tr = (1.f - F) * BTDF_div_ft(wo, wh2, wi, eta, l.ax, l.ay, true);
                 se.f = tr * l.kr;
                 se.pdf = PDF_wi_transmission(wo, new_wh, wi, eta, l.ax, l.ay) * (1.f - dielectric_refl_prob(l, F));
                 se.flags = flag::GlossyTrans;
@@ -650,7 +660,7 @@ VD ScatterEval eval_local(const LobeLuts &S, const Lobe &l, V3 wo, V3 wi, float 
             float ltc = cosine_hemisphere_PDF(cos_theta(w)) * jacobian;
             se.f = l.kr * ltc / cos_i;
             se.pdf = ltc;
-            if (cos_i < 0.f || cos_o < 0.f) se.f = mk3(0.f);
+            if (cos_i < 0.f || cos_o < 0.f) se.f = mks(0.f);
             break;
         }
     }
@@ -689,7 +699,7 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
         }
         case LB_PLASTIC: { // PlasticLobe::sample_wi_local_impl plastic.cpp:45-59: 2 + 1 draws, 2 more on the diffuse branch
             V3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
-            V3 F = l.fr.evaluate(abs_cos_theta(wo));
+            Spec F = l.fr.evaluate(abs_cos_theta(wo));
             float uc = sampler.next_1d();
             if (uc < average(F)) { wi = reflect(wo, wh); *valid = same_hemisphere(wo, wi); }
             else wi = square_to_cosine_hemisphere(sampler.next_2d());
@@ -698,7 +708,7 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
         case LB_DIELECTRIC: { // lobe.cpp:431-449
             V3 wh = sample_wh(wo, sampler.next_2d(), l.ax, l.ay);
             float d = dot(wo, wh);
-            V3 F = l.fr.evaluate(abs_(d));
+            Spec F = l.fr.evaluate(abs_(d));
             float uc = sampler.next_1d();
             if (uc < dielectric_refl_prob(l, F)) {
                 wi = reflect(wo, wh);
@@ -726,7 +736,7 @@ VD V3 sample_wi_local(const Lobe &l, V3 wo, Sampler &sampler, bool *valid) {
 // shaded, so the caller parks the 20 dwords of the lobe there ([field][lane], one ds_write each) and the callee reads them
 // with ds_read — instead of 20 scratch stores in the caller and 20 flat loads (64-bit address arithmetic, HBM-backed,
 // counted on vmcnt and lgkmcnt) at the top of the callee, three times per vertex.  `lds` is the lane's byte offset in LDS.
-constexpr uint32_t kLobeLdsDwords = 20; // x 64 lanes x 4 B = 5 KiB <= sizeof(WaveScratch)
+constexpr uint32_t kLobeLdsDwords = 20 + 4 * (kSpecDim - 3u); // x 64 lanes x 4 B = 5 KiB (6 KiB with four wavelengths) <= sizeof(WaveScratch)
 #define VMK_AS3 __attribute__((address_space(3)))
 VD void stage_lobe(uint32_t lds, const Lobe &l) {
     VMK_AS3 uint32_t *p = reinterpret_cast<VMK_AS3 uint32_t *>(lds);
@@ -735,7 +745,11 @@ VD void stage_lobe(uint32_t lds, const Lobe &l) {
     bits |= l.fr.eta_sp ? 2u : 0u;
 #endif
     const uint32_t w[kLobeLdsDwords] = {(uint32_t) l.kind, f2u(l.kr.x), f2u(l.kr.y), f2u(l.kr.z), f2u(l.rs.x), f2u(l.rs.y), f2u(l.rs.z), f2u(l.A), f2u(l.B), f2u(l.ax), f2u(l.ay),
-                                        (uint32_t) l.fr.kind, f2u(l.fr.a.x), f2u(l.fr.a.y), f2u(l.fr.a.z), f2u(l.fr.b.x), f2u(l.fr.b.y), f2u(l.fr.b.z), f2u(l.fr.eta), bits};
+                                        (uint32_t) l.fr.kind, f2u(l.fr.a.x), f2u(l.fr.a.y), f2u(l.fr.a.z), f2u(l.fr.b.x), f2u(l.fr.b.y), f2u(l.fr.b.z), f2u(l.fr.eta), bits
+#if VMK_SPEC_DIM == 4
+                                        , f2u(l.kr.w), f2u(l.rs.w), f2u(l.fr.a.w), f2u(l.fr.b.w)
+#endif
+    };
 #pragma unroll
     for (uint32_t k = 0; k < kLobeLdsDwords; ++k) p[k * 64u] = w[k];
 }
@@ -745,16 +759,22 @@ VD Lobe staged_lobe(uint32_t lds) {
 #pragma unroll
     for (uint32_t k = 0; k < kLobeLdsDwords; ++k) w[k] = p[k * 64u];
     Lobe l;
+#if VMK_SPEC_DIM == 4
+    l.kind = (int) w[0]; l.kr = {u2f(w[1]), u2f(w[2]), u2f(w[3]), u2f(w[20])}; l.rs = {u2f(w[4]), u2f(w[5]), u2f(w[6]), u2f(w[21])};
+    l.A = u2f(w[7]); l.B = u2f(w[8]); l.ax = u2f(w[9]); l.ay = u2f(w[10]);
+    l.fr.kind = (int) w[11]; l.fr.a = {u2f(w[12]), u2f(w[13]), u2f(w[14]), u2f(w[22])}; l.fr.b = {u2f(w[15]), u2f(w[16]), u2f(w[17]), u2f(w[23])}; l.fr.eta = u2f(w[18]);
+#else
     l.kind = (int) w[0]; l.kr = mk3(u2f(w[1]), u2f(w[2]), u2f(w[3])); l.rs = mk3(u2f(w[4]), u2f(w[5]), u2f(w[6]));
     l.A = u2f(w[7]); l.B = u2f(w[8]); l.ax = u2f(w[9]); l.ay = u2f(w[10]);
     l.fr.kind = (int) w[11]; l.fr.a = mk3(u2f(w[12]), u2f(w[13]), u2f(w[14])); l.fr.b = mk3(u2f(w[15]), u2f(w[16]), u2f(w[17])); l.fr.eta = u2f(w[18]);
+#endif
     l.compensate = (w[19] & 1u) != 0u; l.weight = 1.f; l.sample_weight = 1.f; // (the weights are the caller's business)
 #if VMK_HERO
     l.fr.eta_sp = (w[19] & 2u) != 0u;
 #endif
     return l;
 }
-// Results come back BY VALUE (6 and 5 dwords: VGPR returns under the AMDGPU calling convention), the sampler state goes
+// Results come back BY VALUE (6 — 7 with four wavelengths — and 5 dwords: VGPR returns under the AMDGPU calling convention), the sampler state goes
 // in and out by value too: no pointer into the caller's private frame crosses the call, so nothing of the caller's is
 // forced into scratch and no flat access to the stack aperture exists in these routines.
 struct EvalRet { ScatterEval se; float eta; };
@@ -851,8 +871,8 @@ VD void microfacet_alpha(const DScene &S, const vmk_material *m, int slot_r, int
     *ax = a.x; *ay = a.y;
 }
 VD void lobe_defaults(Lobe &l) {
-    l.kind = LB_LAMBERT; l.kr = mk3(1.f); l.rs = mk3(0.f); l.A = 0.f; l.B = 0.f; l.ax = 0.f; l.ay = 0.f;
-    l.fr.kind = FR_CONSTANT; l.fr.a = mk3(1.f); l.fr.b = mk3(0.f); l.fr.eta = 1.f;
+    l.kind = LB_LAMBERT; l.kr = mks(1.f); l.rs = mks(0.f); l.A = 0.f; l.B = 0.f; l.ax = 0.f; l.ay = 0.f;
+    l.fr.kind = FR_CONSTANT; l.fr.a = mks(1.f); l.fr.b = mks(0.f); l.fr.eta = 1.f;
 #if VMK_HERO
     l.fr.eta_sp = false;
 #endif
@@ -890,7 +910,7 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
         case VMK_MAT_PLASTIC: { // plastic.cpp:103-122 (same double roughness_to_alpha as substrate)
             l.kind = LB_PLASTIC;
             l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A);
-            V3 Rs = eval_slot_albedo(S, m->slot[1], it.uv, cnt SWL_A);
+            Spec Rs = eval_slot_albedo(S, m->slot[1], it.uv, cnt SWL_A);
             float ior = eval_slot1(S, m->slot[2], it.uv, cnt);
             float ax, ay; microfacet_alpha(S, m, 3, 4, it.uv, 0.0001f, &ax, &ay, cnt);
             if (m->flags & VMK_MATF_REMAP_ROUGHNESS) { ax = sqr(ax); ay = sqr(ay); }
@@ -901,11 +921,11 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
         case VMK_MAT_METALLIC: { // metallic.cpp:42-60: MetallicLobe = PureReflectionLobe with compensation, F82-tint Fresnel
             l.kind = LB_MICROFACET; l.kr = eval_slot_albedo(S, m->slot[0], it.uv, cnt SWL_A);
             microfacet_alpha(S, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay, cnt);
-            V3 edge_tint = eval_slot_albedo(S, m->slot[1], it.uv, cnt SWL_A);
+            Spec edge_tint = eval_slot_albedo(S, m->slot[1], it.uv, cnt SWL_A);
             const float f = 6.f / 7.f;
             const float f5 = pow5(f);
-            V3 f_schlick = lerp3(f5, l.kr, mk3(1.f)); // FresnelF82Tint::init_from_F82 fresnel.h:115-121
-            l.fr.kind = FR_F82; l.fr.a = l.kr; l.fr.b = f_schlick * (7.f / (f5 * f)) * (mk3(1.f) - edge_tint);
+            Spec f_schlick = lerp3(f5, l.kr, mks(1.f)); // FresnelF82Tint::init_from_F82 fresnel.h:115-121
+            l.fr.kind = FR_F82; l.fr.a = l.kr; l.fr.b = f_schlick * (7.f / (f5 * f)) * (mks(1.f) - edge_tint);
             l.compensate = true;
             break;
         }
@@ -914,8 +934,8 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
             float cos_t = dot(it.wo, it.ng);
 #if VMK_HERO
             if (m->slot[1].tex == VMK_SLOT_SPD) { // dispersive: one ior per wavelength, directions follow the hero wavelength (eta[0])
-                V3 iors = eval_slot_spd(S, m->slot[1], it.uv, cnt SWL_A);
-                iors = cos_t > 0.f ? iors : V3{rcp(iors.x), rcp(iors.y), rcp(iors.z)};
+                Spec iors = eval_slot_spd(S, m->slot[1], it.uv, cnt SWL_A);
+                iors = cos_t > 0.f ? iors : smap(iors, [](float v) { return rcp(v); });
                 microfacet_alpha(S, m, 2, 3, it.uv, 0.01f, &l.ax, &l.ay, cnt);
                 l.fr.kind = FR_DIELECTRIC; l.fr.eta = iors.x; l.fr.a = iors; l.fr.eta_sp = true;
                 break;
@@ -939,9 +959,8 @@ VD void build_simple_lobe(const DScene &S, const vmk_material *m, const Interact
     }
 }
 
-VD V3 layering_weight(V3 layer_albedo, V3 weight) { // principled_bsdf.cpp:209-214
-    V3 tmp = {weight.x == 0.f ? 0.f : layer_albedo.x / weight.x, weight.y == 0.f ? 0.f : layer_albedo.y / weight.y,
-              weight.z == 0.f ? 0.f : layer_albedo.z / weight.z};
+VD Spec layering_weight(Spec layer_albedo, Spec weight) { // principled_bsdf.cpp:209-214
+    Spec tmp = smap2(layer_albedo, weight, [](float a, float w) { return w == 0.f ? 0.f : a / w; });
     return weight * saturate_(1.f - max_comp(tmp));
 }
 // Per-hit material context: what create_lobe_set computes once.  Principled keeps only the per-lobe colours
@@ -959,9 +978,9 @@ struct MatCtx {
     int pchild;              // mix / add: which child (0 / 1) is the principled one, -1: both are single-lobe
     // principled
     int first;    // 0 with sheen, 1 without
-    V3 color, spec_tint, kr_sheen, kr_coat, kr_metal, kr_spec, kr_diff;
+    Spec color, spec_tint, kr_sheen, kr_coat, kr_metal, kr_spec, kr_diff;
     float sheen_a, sheen_b, ax, ay, cc_alpha, cc_ior, ior, eta, w_trans;
-    V3 f82_b, f0_spec, f0_trans;
+    Spec f82_b, f0_spec, f0_trans;
     float sw[6];
 };
 // FULL = the scene contains mix / principled_bsdf materials.  Like the reference, which JIT-compiles only the material
@@ -1005,7 +1024,7 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
     mc.spec_tint = eval_slot_albedo(S, m->slot[VMK_P_SPEC_TINT], uv, cnt SWL_A);
     float aspect = sqrt_(1.f - anisotropic * 0.9f);
     mc.ax = fmax_(0.001f, sqr(roughness) / aspect); mc.ay = fmax_(0.001f, sqr(roughness) * aspect);
-    V3 weight = mk3(1.f);
+    Spec weight = mks(1.f);
     float cos_t = dot(it.wo, it.ng);
     float front_factor = cos_t > 0.f ? 1.f : 0.f;
 #pragma unroll
@@ -1013,7 +1032,7 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
     mc.first = 1;
     if (S.lut_sheen_approx) { // sheen (SheenLTC ctor principled_bsdf.cpp:37-45)
         mc.first = 0;
-        V3 sheen_tint = eval_slot_albedo(S, m->slot[VMK_P_SHEEN_TINT], uv, cnt SWL_A);
+        Spec sheen_tint = eval_slot_albedo(S, m->slot[VMK_P_SHEEN_TINT], uv, cnt SWL_A);
         float sheen_weight = eval_slot1(S, m->slot[VMK_P_SHEEN_WEIGHT], uv, cnt) * front_factor;
         float sheen_roughness = eval_slot1(S, m->slot[VMK_P_SHEEN_ROUGHNESS], uv, cnt);
         float c[4]; sample_lut2d<4>(S.lut_sheen_approx, cos_t, sheen_roughness, c);
@@ -1028,12 +1047,12 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
         cc_roughness = sqr(cc_roughness);
         mc.cc_alpha = cc_roughness;
         mc.cc_ior = eval_slot1(S, m->slot[VMK_P_COAT_IOR], uv, cnt);
-        V3 cc_tint = eval_slot_albedo(S, m->slot[VMK_P_COAT_TINT], uv, cnt SWL_A);
+        Spec cc_tint = eval_slot_albedo(S, m->slot[VMK_P_COAT_TINT], uv, cnt SWL_A);
         mc.kr_coat = (weight * cc_weight) * cc_tint;
         float x = sqrt_(sqrt_(cc_roughness * cc_roughness));
         float z = inverse_lerp(mc.cc_ior, 1.003f, 4.f);
         float sv; sample_lut3d<1>(S.lut_coat, mk3(x, cos_t, z), &sv);
-        V3 albedo = mc.kr_coat * sv;
+        Spec albedo = mc.kr_coat * sv;
         mc.sw[1] = average(albedo);
         weight = layering_weight(albedo, weight);
     }
@@ -1041,8 +1060,8 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
         float metallic = eval_slot1(S, m->slot[VMK_P_METALLIC], uv, cnt) * front_factor;
         const float f = 6.f / 7.f;
         const float f5 = pow5(f);
-        V3 f_schlick = lerp3(f5, mc.color, mk3(1.f));
-        mc.f82_b = f_schlick * (7.f / (f5 * f)) * (mk3(1.f) - mc.spec_tint);
+        Spec f_schlick = lerp3(f5, mc.color, mks(1.f));
+        mc.f82_b = f_schlick * (7.f / (f5 * f)) * (mks(1.f) - mc.spec_tint);
         mc.kr_metal = weight * metallic;
         mc.sw[2] = metallic * average(weight);
         weight *= (1.0f - metallic);
@@ -1050,7 +1069,7 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
     { // transmission
         float trans_weight = eval_slot1(S, m->slot[VMK_P_TRANS_WEIGHT], uv, cnt);
         mc.eta = cos_t > 0.f ? mc.ior : rcp(mc.ior);
-        V3 t_weight = weight * trans_weight;
+        Spec t_weight = weight * trans_weight;
         mc.f0_trans = mc.spec_tint * schlick_F0_from_ior(mc.eta);
         mc.w_trans = average(t_weight);
         mc.sw[3] = mc.w_trans;
@@ -1063,7 +1082,7 @@ VD void mat_prepare(const DScene &S, const vmk_material *m, const Interaction &i
         float x = sqrt_(sqrt_(mc.ax * mc.ay));
         float z = sqrt_(abs_((mc.ior - 1.0f) / (mc.ior + 1.0f)));
         float sv; sample_lut3d<1>(S.lut_specular, mk3(x, cos_t, z), &sv);
-        V3 albedo = lerp3(sv, mc.f0_spec, mk3(1.f)) * mc.kr_spec;
+        Spec albedo = lerp3(sv, mc.f0_spec, mks(1.f)) * mc.kr_spec;
         mc.sw[4] = average(albedo);
         weight = layering_weight(albedo, weight);
     }
@@ -1154,7 +1173,7 @@ VD ScatterEval mat_evaluate_world(const DScene &S, const MatCtx &mc, const Inter
         se.f *= abs_cos_theta(wi);
         return se;
     }
-    ScatterEval ret; ret.f = mk3(0.f); ret.pdf = 0.f; ret.flags = flag::Unset;
+    ScatterEval ret; ret.f = mks(0.f); ret.pdf = 0.f; ret.flags = flag::Unset;
     bool sh_world = same_hemisphere(world_wo, world_wi, it.shading.z);
 #pragma unroll 1
     for (int i = 0; i < mc.n; ++i) {
@@ -1229,7 +1248,7 @@ VD void mat_evaluate_and_sample(const DScene &S, const MatCtx &mc, const Interac
 // a7-a10. lights — base/illumination/lightsampler.cpp, render_core/light/{area,environments/spherical}.cpp,
 //                  render_core/warper/{alias.h,alias2d.cpp}
 // =====================================================================================================
-struct LightEval { V3 L; float pdf; };
+struct LightEval { Spec L; float pdf; };
 struct LightSample { LightEval eval; V3 p_light; };
 
 VD void alias_offset_u_remapped(const DScene &S, uint32_t base, uint32_t size, float u, uint32_t *idx_out, float *u_remapped) { // alias.h:148-158
@@ -1288,8 +1307,8 @@ VD void light_select(const DScene &S, const vmk_render_params *P, float u, uint3
     *index = light_select_inner(S, P, u);
     *pmf = light_pmf_inner(S, P, *index);
 }
-VD V3 area_L(const DScene &S, const vmk_light *l, V2 uv, V3 ng, V3 w, DCounters &cnt SWL_P) { // area.cpp:91-95
-    V3 radiance = eval_slot_illumination(S, l->color, uv, cnt SWL_A) * l->scale;
+VD Spec area_L(const DScene &S, const vmk_light *l, V2 uv, V3 ng, V3 w, DCounters &cnt SWL_P) { // area.cpp:91-95
+    Spec radiance = eval_slot_illumination(S, l->color, uv, cnt SWL_A) * l->scale;
     return radiance * ((dot(w, ng) > 0.f || l->two_sided) ? 1.f : 0.f);
 }
 VD float area_PDF_wi(float pdf_pos, V3 ng, V3 w) { // area.cpp:114-118
@@ -1313,7 +1332,7 @@ VD LightSample area_sample_wi(const DScene &S, const vmk_render_params *P, const
     ret.p_light = robust_pos(it.pos, it.ng, w, P->ray_offset_factor);
     return ret;
 }
-VD V3 env_L(const DScene &S, const vmk_light *l, V3 local_dir, DCounters &cnt SWL_P) { // spherical.cpp:60-68
+VD Spec env_L(const DScene &S, const vmk_light *l, V3 local_dir, DCounters &cnt SWL_P) { // spherical.cpp:60-68
     V2 uv = {spherical_phi(local_dir) * Inv2Pi, spherical_theta(local_dir) * InvPi};
     return eval_slot_illumination(S, l->color, uv, cnt SWL_A) * l->scale;
 }
@@ -1364,7 +1383,7 @@ VD LightSample point_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, DC
     LightSample ls;
     V3 pos = ld3(l->position);
     V3 w_un = p_ref - pos;
-    V3 value = eval_slot_illumination(S, l->color, V2{0.f, 0.f}, cnt SWL_A) * l->scale;
+    Spec value = eval_slot_illumination(S, l->color, V2{0.f, 0.f}, cnt SWL_A) * l->scale;
     if (l->type == VMK_LIGHT_SPOT) {
         V3 w = normalize(w_un);
         float cos_theta = clamp_(dot(ld3(l->direction), w), l->cos_angle, l->cos_falloff_start);
@@ -1388,7 +1407,7 @@ VD LightSample light_sample_wi(const DScene &S, const vmk_render_params *P, V3 p
     return ls;
 }
 VD LightEval light_evaluate_hit_wi(const DScene &S, const vmk_render_params *P, V3 p_ref, const Interaction &it, DCounters &cnt SWL_P) { // lightsampler.cpp:252-267
-    LightEval ret; ret.L = mk3(0.f); ret.pdf = 0.f;
+    LightEval ret; ret.L = mks(0.f); ret.pdf = 0.f;
     const vmk_light *l = S.lights + it.light_id;
     if (l->type != VMK_LIGHT_AREA) return ret;
     float pdf_pos = (1.f / it.prim_area) * alias_PMF(S, l, it.prim_id);

@@ -22,7 +22,9 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------------------------------------
 struct PathState {
     Ray ray;
-    V3 L, T, prev_ng;
+    V3 L;     // linear sRGB
+    Spec T;   // throughput: a spectrum over the path's wavelengths
+    V3 prev_ng;
     float scatter_pdf, eta_scale;
     uint32_t bounces;
     uint32_t medium; // RayState::medium: the medium the current ray travels in (MEDIA variants only)
@@ -31,20 +33,20 @@ struct PathState {
 #endif
 };
 __device__ __forceinline__ void path_begin(PathState &ps, const vmk_render_params *P) {
-    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
+    ps.L = mk3(0.f); ps.T = mks(1.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.prev_ng = ps.ray.d; ps.bounces = 0;
     ps.medium = P->process_mediums ? P->camera_medium : VMK_INVALID; // sensor.cpp:48
 }
 
 // ---- homogeneous medium + Henyey-Greenstein (render_core/medium/homogeneous.cpp:30-70, interaction.h:136-139,
 //      interaction.cpp:12-32,114-134, geometry.cpp:187-199) — §8f rank 1 ----
 // sigma_t / sigma_s as spectra: decode_to_unbound_spectrum of the RGB coefficients (homogeneous.cpp:34,54-55)
-VD V3 medium_sigma_t(const DScene &S, const vmk_medium *m SWL_P) { return spec_unbound(S, (ld3(m->sigma_a) + ld3(m->sigma_s)) * m->scale SWL_A); }
-VD V3 medium_sigma_s(const DScene &S, const vmk_medium *m SWL_P) { return spec_unbound(S, ld3(m->sigma_s) * m->scale SWL_A); }
-VD V3 exp3(V3 v) { return {exp_(v.x), exp_(v.y), exp_(v.z)}; }
-VD V3 medium_Tr(const DScene &S, const vmk_medium *m, float t SWL_P) { return exp3((-1.f * medium_sigma_t(S, m SWL_A)) * fmin_(RayTMax, t)); }
-VD V3 geometry_Tr(const DScene &S, const vmk_render_params *P, const Ray &r, uint32_t medium SWL_P) {
+VD Spec medium_sigma_t(const DScene &S, const vmk_medium *m SWL_P) { return spec_unbound(S, (ld3(m->sigma_a) + ld3(m->sigma_s)) * m->scale SWL_A); }
+VD Spec medium_sigma_s(const DScene &S, const vmk_medium *m SWL_P) { return spec_unbound(S, ld3(m->sigma_s) * m->scale SWL_A); }
+VD Spec exp3(Spec v) { return smap(v, [](float x) { return exp_(x); }); }
+VD Spec medium_Tr(const DScene &S, const vmk_medium *m, float t SWL_P) { return exp3((-1.f * medium_sigma_t(S, m SWL_A)) * fmin_(RayTMax, t)); }
+VD Spec geometry_Tr(const DScene &S, const vmk_render_params *P, const Ray &r, uint32_t medium SWL_P) {
     if (P->process_mediums && medium != VMK_INVALID) return medium_Tr(S, S.mediums + medium, length(r.d) * r.t_max SWL_A);
-    return mk3(1.f);
+    return mks(1.f);
 }
 VD float phase_HG(float cos_theta, float g) {
     float denom = 1.f + sqr(g) + 2.f * g * cos_theta;
@@ -93,7 +95,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
     Ray shadow_ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
     if (active && !found) { // evaluate_miss integrator.cpp:137-158
         if (S.env_light != VMK_INVALID) {
-            V3 tr = mk3(1.f);
+            Spec tr = mks(1.f);
             if constexpr (MEDIA) { // :146-151: a ray that leaves the scene inside a medium is attenuated over world_diameter
                 if (P->process_mediums) {
                     ps.ray.t_max = S.lights[S.env_light].world_diameter;
@@ -118,9 +120,9 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
             ps.ray.t_max = length(it.pos - ps.ray.o) / length(ps.ray.d);                                   // geometry.h:64-69
             if (P->process_mediums && ps.medium != VMK_INVALID) { // HomogeneousMedium::sample, 2 draws (integrator.cpp:199-206)
                 const vmk_medium *m = S.mediums + ps.medium;
-                V3 sigma_t = medium_sigma_t(S, m SWL_A), sigma_s = medium_sigma_s(S, m SWL_A);
-                uint32_t channel = (uint32_t) (sampler.next_1d() * 3.f); if (channel > 2u) channel = 2u;
-                float st_c = channel == 0 ? sigma_t.x : (channel == 1 ? sigma_t.y : sigma_t.z);
+                Spec sigma_t = medium_sigma_t(S, m SWL_A), sigma_s = medium_sigma_s(S, m SWL_A);
+                uint32_t channel = (uint32_t) (sampler.next_1d() * (float) kSpecDim); if (channel > kSpecDim - 1u) channel = kSpecDim - 1u;
+                float st_c = scomp(sigma_t, channel);
                 float dist = -log_(1.f - sampler.next_1d()) / st_c;
                 float t = fmin_(dist / length(ps.ray.d), ps.ray.t_max);
                 bool sampled_medium = t < ps.ray.t_max;
@@ -129,9 +131,9 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
                     it.mat_id = VMK_INVALID; it.light_id = VMK_INVALID; it.prim_id = VMK_INVALID; it.prim_area = 0.f;
                     has_phase = true; phase_g = m->g; med_in = ps.medium; med_out = ps.medium;
                 }
-                V3 tr = medium_Tr(S, m, t SWL_A);
-                V3 density = sampled_medium ? sigma_t * tr : tr;
-                float pdf = (density.x + density.y + density.z) / 3.f;
+                Spec tr = medium_Tr(S, m, t SWL_A);
+                Spec density = sampled_medium ? sigma_t * tr : tr;
+                float pdf = average(density);
                 ps.T *= sampled_medium ? tr * sigma_s / pdf : tr / pdf;
             }
         }
@@ -145,7 +147,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
                 LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt SWL_A);
                 float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
                 weight = mis_mode == 2 ? 1.f : (mis_mode == 1 ? (ps.bounces == 0 ? weight : 0.f) : weight);
-                V3 tr = mk3(1.f);
+                Spec tr = mks(1.f);
                 if constexpr (MEDIA) tr = geometry_Tr(S, P, ps.ray, ps.medium SWL_A);
                 ps.L += spec_linear_srgb(S, ev.L * ps.T * weight * tr SWL_A);
             }
@@ -162,16 +164,16 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
     Hit sh;
     bool occluded = traverse_wave<COUNT, DEEP>(S, shadow_ray, shade, true, ws, sh, cnt);
     if (!shade) return pass_through ? kPathGoOn : kPathEnd;
-    V3 tr_shadow = mk3(1.f);
+    Spec tr_shadow = mks(1.f);
     if constexpr (MEDIA) tr_shadow = geometry_Tr(S, P, shadow_ray, P->process_mediums ? (dot(it.ng, shadow_ray.d) > 0.f ? med_out : med_in) : VMK_INVALID SWL_A);
     V3 wi = normalize(ls.p_light - it.pos);
     ScatterEval se; BSDFSample bs;
     if (MEDIA && has_phase) { // integrator.cpp:271-279: the phase function stands in for the BSDF (2 draws)
         float f = phase_HG(dot(it.wo, wi), phase_g);
-        se.f = mk3(f); se.pdf = f; se.flags = 0;
+        se.f = mks(f); se.pdf = f; se.flags = 0;
         float fs;
         bs.wi = hg_sample(it.wo, phase_g, sampler, &fs);
-        bs.eval.f = mk3(fs); bs.eval.pdf = fs; bs.eval.flags = 0; bs.eta = 1.f;
+        bs.eval.f = mks(fs); bs.eval.pdf = fs; bs.eval.flags = 0; bs.eta = 1.f;
     } else {
         // material: evaluate towards the light, then sample (direct_lighting integrator.cpp:20-37)
         MatCtx mc;
@@ -182,7 +184,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
         mat_prepare<FULL>(S, S.materials + it.mat_id, it, mc, cnt SWL_A);
 #if VMK_HERO
         // SampledWavelengths::check_dispersive (spectrum.cpp:32-39, integrator.cpp:264): a dispersive lobe keeps the hero wavelength only
-        if (S.materials[it.mat_id].type == VMK_MAT_GLASS && (S.materials[it.mat_id].flags & VMK_MATF_DISPERSIVE)) { swl.pdf.y = 0.f; swl.pdf.z = 0.f; }
+        if (S.materials[it.mat_id].type == VMK_MAT_GLASS && (S.materials[it.mat_id].flags & VMK_MATF_DISPERSIVE)) { Spec keep = mks(0.f); keep.x = swl.pdf.x; swl.pdf = keep; } // invalidation_secondary (spectrum.cpp:21-30)
 #endif
         mat_evaluate_and_sample<FULL>(S, mc, it, wi, sampler, se, bs, cnt SWL_A);
     }
@@ -194,7 +196,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
     bool is_delta_light = ls.eval.pdf < 0.f;
     float weight = mis_mode != 1 ? (is_delta_light ? 1.f : MIS_weight(ls.eval.pdf, se.pdf)) : 1.f;
     ls.eval.pdf = is_delta_light ? -ls.eval.pdf : ls.eval.pdf;
-    V3 Ld = mk3(0.f);
+    Spec Ld = mks(0.f);
     if (!occluded && se.pdf > 0.f && ls.eval.pdf > 0.f) Ld = ls.eval.L * se.f * weight / ls.eval.pdf;
     if (mis_mode == 2) Ld = Ld * 0.f;
     ps.L += spec_linear_srgb(S, ps.T * Ld * tr_shadow SWL_A);
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
     Sampler sampler; sampler.state = 0;
     PathState ps;
     ps.ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
-    ps.L = mk3(0.f); ps.T = mk3(1.f); ps.prev_ng = mk3(0.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.bounces = 0; ps.medium = VMK_INVALID;
+    ps.L = mk3(0.f); ps.T = mks(1.f); ps.prev_ng = mk3(0.f); ps.scatter_pdf = 1e16f; ps.eta_scale = 1.f; ps.bounces = 0; ps.medium = VMK_INVALID;
 #if VMK_HERO
-    ps.swl.lambda = mk3(538.f); ps.swl.pdf = mk3(1.f);
+    ps.swl.lambda = mks(538.f); ps.swl.pdf = mks(1.f);
 #endif
 
 #ifdef VMK_DIAG
@@ -385,35 +387,80 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
 // the oracle's path records.  Output: 8 floats per vertex for the first 8 vertices, then L (o[64..66]).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kUnitPathVertexCap = 1 << 16; // a safety net far above anything a real path reaches (k_render has no cap either)
-__device__ __forceinline__ void unit_path(const DScene &S, const vmk_render_params *P, WaveScratch *ws, bool live, uint32_t px, uint32_t py, uint32_t frame, float *o, DCounters &cnt) {
-    Sampler smp; smp.start(px, py, frame, 0);
-    PathState ps; ps.ray = generate_ray(P, px, py, smp);
+// Between two vertices the unit kernel keeps its path state in LDS, not in registers: every iteration reloads (ray, L, T, ...)
+// through volatile accesses and stores them back after path_bounce.  The twin then shares no loop-carried register allocation with
+// the megakernel it checks — the place both miscompiles of this toolchain showed up — and costs the
+// megakernel nothing.
+constexpr uint32_t kUnitStateDwords = 22u + 3u * kSpecDim; // ray 7, L 3, prev_ng 3, T, 4 scalars, sampler, (hero: lambda, pdf), padding for srgb
+struct UnitState { uint32_t w[kUnitStateDwords][64]; };
+__device__ __forceinline__ void unit_state_store(UnitState *us, const PathState &ps, const Sampler &smp) {
+    volatile uint32_t *q = &us->w[0][threadIdx.x & 63u];
+    uint32_t k = 0;
+    auto put = [&](float v) { q[(k++) * 64u] = f2u(v); };
+    put(ps.ray.o.x); put(ps.ray.o.y); put(ps.ray.o.z); put(ps.ray.d.x); put(ps.ray.d.y); put(ps.ray.d.z); put(ps.ray.t_max);
+    put(ps.L.x); put(ps.L.y); put(ps.L.z); put(ps.prev_ng.x); put(ps.prev_ng.y); put(ps.prev_ng.z);
+    put(ps.scatter_pdf); put(ps.eta_scale); put(u2f(ps.bounces)); put(u2f(ps.medium)); put(u2f(smp.state));
+#pragma unroll
+    for (uint32_t i = 0; i < kSpecDim; ++i) put(scomp(ps.T, i));
 #if VMK_HERO
-    smp.start(px, py, frame, 0xFFFFFFFFu); // RenderEnv::initial
-    ps.swl = sample_wavelengths(smp);
+#pragma unroll
+    for (uint32_t i = 0; i < kSpecDim; ++i) { put(scomp(ps.swl.lambda, i)); put(scomp(ps.swl.pdf, i)); }
 #endif
-    smp.start(px, py, frame, 1);
-    path_begin(ps, P);
+}
+__device__ __forceinline__ void unit_state_load(const UnitState *us, PathState &ps, Sampler &smp) {
+    const volatile uint32_t *q = &us->w[0][threadIdx.x & 63u];
+    uint32_t k = 0;
+    auto get = [&]() { return u2f(q[(k++) * 64u]); };
+    ps.ray.o.x = get(); ps.ray.o.y = get(); ps.ray.o.z = get(); ps.ray.d.x = get(); ps.ray.d.y = get(); ps.ray.d.z = get(); ps.ray.t_max = get();
+    ps.L.x = get(); ps.L.y = get(); ps.L.z = get(); ps.prev_ng.x = get(); ps.prev_ng.y = get(); ps.prev_ng.z = get();
+    ps.scatter_pdf = get(); ps.eta_scale = get(); ps.bounces = f2u(get()); ps.medium = f2u(get()); smp.state = f2u(get());
+#pragma unroll
+    for (uint32_t i = 0; i < kSpecDim; ++i) sput(ps.T, i, get());
+#if VMK_HERO
+#pragma unroll
+    for (uint32_t i = 0; i < kSpecDim; ++i) { sput(ps.swl.lambda, i, get()); sput(ps.swl.pdf, i, get()); }
+#endif
+}
+__device__ __forceinline__ void unit_path(const DScene &S, const vmk_render_params *P, WaveScratch *ws, UnitState *us, bool live, uint32_t px, uint32_t py, uint32_t frame, float *o, DCounters &cnt) {
+    {
+        Sampler smp; smp.start(px, py, frame, 0);
+        PathState ps; ps.ray = generate_ray(P, px, py, smp);
+#if VMK_HERO
+        smp.start(px, py, frame, 0xFFFFFFFFu); // RenderEnv::initial
+        ps.swl = sample_wavelengths(smp);
+#endif
+        smp.start(px, py, frame, 1);
+        path_begin(ps, P);
+        unit_state_store(us, ps, smp);
+    }
     bool alive = live;
     for (int v = 0; v < kUnitPathVertexCap && __any(alive); ++v) { // wave-uniform trip count: path_bounce is wave-cooperative
         float dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        PathState ps; Sampler smp;
+        unit_state_load(us, ps, smp);
         int st = path_bounce<true, true, true, true>(S, P, ws, ps, smp, cnt, dbg, alive); // (DEEP: the unit kernel serves every tree)
+        if (alive) unit_state_store(us, ps, smp);
         if (alive && v < 8) for (int k = 0; k < 8; ++k) o[v * 8 + k] = dbg[k];
         if (st == kPathTail && alive) st = tail_is_primary(P, px, py, frame, ps.ray.d) ? kPathEnd : kPathGoOn;
         if (st != kPathGoOn) alive = false;
     }
-    if (live) { o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z; }
+    if (live) {
+        PathState ps; Sampler smp;
+        unit_state_load(us, ps, smp);
+        o[64] = ps.L.x; o[65] = ps.L.y; o[66] = ps.L.z;
+    }
 }
 // in: 3 uint32 (px, py, frame) per path; out: >= 67 floats per path; launched with 64-thread blocks
 __global__ void k_unit_path(const DScene *scene, const vmk_render_params *P, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
     __shared__ WaveScratch s_ws[1];
+    __shared__ UnitState s_us[1];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const float *a = in + (size_t) (live ? i : 0) * in_stride;
     float *o = out + (size_t) (live ? i : 0) * out_stride;
     DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
     const DScene S = *scene;
-    unit_path(S, P, s_ws, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
+    unit_path(S, P, s_ws, s_us, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
 }
 
 // the twelve ahead-of-time variants: <FULL, MEDIA> x {tallying, not tallying} for trees that fit the LDS stack, and the tallying

@@ -25,10 +25,13 @@
 
 using namespace vmkd;
 
-// the hero-spectrum instance of the megakernel lives in vmk_hero.hip
-hipError_t vmk_hero_occupancy(bool full, bool media, bool count, bool deep, int *blocks_per_cu);
-hipError_t vmk_hero_launch_unit_path(hipStream_t stream, const void *scene, const void *params, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride);
-hipError_t vmk_hero_launch_render(bool full, bool media, bool count, bool deep, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
+// the hero-spectrum instances of the megakernel live in vmk_hero.hip (3 wavelengths per path) and vmk_hero4.hip (4)
+#define VMK_HERO_DECL(prefix) \
+hipError_t prefix##occupancy(bool full, bool media, bool count, bool deep, int *blocks_per_cu); \
+hipError_t prefix##launch_unit_path(hipStream_t stream, const void *scene, const void *params, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride); \
+hipError_t prefix##launch_render(bool full, bool media, bool count, bool deep, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
+VMK_HERO_DECL(vmk_hero_)
+VMK_HERO_DECL(vmk_hero4_)
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -295,6 +298,7 @@ __global__ void k_tonemap(const float4 *accum, float4 *out, uint32_t n, float ex
 
 __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t kind, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride) {
     __shared__ WaveScratch s_ws[1]; // launched with 64-thread blocks
+    __shared__ UnitState s_us[1];   // kind 6: the path state between vertices
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     if (!live && kind != 6 && kind != 7 && kind != 8) return; // kinds 6/7 trace rays: every lane of the wave has to stay
@@ -349,7 +353,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
         }
         case 6: { // whole path of one (pixel, frame): 8 floats per vertex for up to 8 vertices, then L (3 floats)
             const DScene S = *scene;
-            unit_path(S, P, s_ws, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
+            unit_path(S, P, s_ws, s_us, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
             break;
         }
 #ifdef VMK_DIAG
@@ -553,6 +557,7 @@ struct vmk_ctx {
     bool full_materials{true}; // scene has mix / principled_bsdf -> lobe-set variant of the megakernel
     bool count_traversal{true}; // vmk_set_traversal_counters: launch the megakernel instance that tallies node fetches / triangle tests
     bool hero{false};          // vmk_scene::spectrum == VMK_SPECTRUM_HERO -> the vmk_hero.hip instance of the megakernel
+    bool hero4{false};         // ... with spectrum_dimension == 4 -> the vmk_hero4.hip instance
     DevBuf<float> rgb2spec, spd;
     uint32_t n_tris{0};
     DevBuf<vmk_tri_pos> tri_pos_in, tri_pos;
@@ -724,6 +729,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     const bool hero = sc->spectrum == VMK_SPECTRUM_HERO;
     if (sc->spectrum != VMK_SPECTRUM_SRGB && !hero) { ctx->error = "vmk_upload_scene: unknown spectrum type"; return VMK_ERR_ARG; }
     auto spd_ok = [&](uint32_t off, uint32_t n) { return n >= 2 && (uint64_t) off + n <= sc->n_spd; };
+    if (hero && sc->spectrum_dimension != 0 && sc->spectrum_dimension != 3 && sc->spectrum_dimension != 4) { ctx->error = "vmk_upload_scene: spectrum/hero is built for 3 or 4 wavelengths per path (vmk_scene::spectrum_dimension)"; return VMK_ERR_UNSUPPORTED; }
     if (hero) {
         if (!sc->rgb2spec || !sc->spd_data || sc->spd_cie_count < 2 || !(sc->spd_cie_interval > 0.f) || !(sc->cie_y_integral > 0.f)) { ctx->error = "vmk_upload_scene: hero spectrum tables missing"; return VMK_ERR_ARG; }
         for (int k = 0; k < 4; ++k) if (!spd_ok(sc->spd_cie[k], sc->spd_cie_count)) { ctx->error = "vmk_upload_scene: CIE tables out of range"; return VMK_ERR_ARG; }
@@ -805,7 +811,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     HIP_TRY(ctx->luts.alloc(total));
     size_t off[6], o = 0;
     for (int i = 0; i < 6; ++i) { off[i] = o; if (src[i]) HIP_TRY(hipMemcpyAsync(ctx->luts.p + o, src[i], sizes[i] * 4, hipMemcpyHostToDevice, st)); o += sizes[i]; }
-    ctx->hero = hero;
+    ctx->hero = hero; ctx->hero4 = hero && sc->spectrum_dimension == 4;
     if (hero) {
         HIP_TRY(ctx->rgb2spec.upload(sc->rgb2spec, (size_t) 3 * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * VMK_RGB2SPEC_RES * 4, st));
         HIP_TRY(ctx->spd.upload(sc->spd_data, sc->n_spd, st));
@@ -1051,7 +1057,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     const bool count = ctx->count_traversal;
     const bool deep = ctx->stack_overflow.p != nullptr;
     auto kernel = select_render_kernel(ctx->full_materials, media, count, deep);
-    if (ctx->hero) HIP_TRY(vmk_hero_occupancy(ctx->full_materials, media, count, deep, &per_cu));
+    if (ctx->hero) HIP_TRY((ctx->hero4 ? vmk_hero4_occupancy : vmk_hero_occupancy)(ctx->full_materials, media, count, deep, &per_cu));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1079,7 +1085,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         HIP_TRY(hipMemsetAsync(ctx->diag.p, 0, (size_t) n_items * 128 * 4, ctx->stream));
         A.diag = ctx->hero ? nullptr : ctx->diag.p;
 #endif
-        if (ctx->hero) HIP_TRY(vmk_hero_launch_render(ctx->full_materials, media, count, deep, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
+        if (ctx->hero) HIP_TRY((ctx->hero4 ? vmk_hero4_launch_render : vmk_hero_launch_render)(ctx->full_materials, media, count, deep, grid, ctx->stream, static_cast<const RenderRest *>(&A), sizeof(RenderRest), &ctx->h_scene, sizeof(DSceneFull)));
         else {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
             HIP_TRY(hipGetLastError());
@@ -1414,7 +1420,7 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
 #ifdef VMK_DIAG
         kind = kind_arg;
 #endif
-        if (ctx->hero && kind == 6) e = vmk_hero_launch_unit_path(ctx->stream, ctx->d_scene.p, ctx->d_params.p, n, di.p, in_stride, dout.p, out_stride);
+        if (ctx->hero && kind == 6) e = (ctx->hero4 ? vmk_hero4_launch_unit_path : vmk_hero_launch_unit_path)(ctx->stream, ctx->d_scene.p, ctx->d_params.p, n, di.p, in_stride, dout.p, out_stride);
         else {
             hipLaunchKernelGGL(k_test, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_scene.p, ctx->d_params.p, kind, n, di.p, in_stride, dout.p, out_stride);
             e = hipGetLastError();

@@ -265,6 +265,7 @@ struct HostScene {
     std::vector<float> luts;
     // hero spectrum (render_core/spectrum/hero.cpp): tabulated spectra pool, CIE tables, metal (eta, k) curves, sRGB uplift table
     bool hero{false};
+    uint32_t spectrum_dimension{3}; // wavelengths per path of spectrum/hero (3 or 4)
     std::string data_dir;            // directory of the albedo-table blob: spectra.bin / srgb2spec.bin live next to it
     std::vector<float> spd;          // vmk_scene.spd_data
     std::vector<float> cie_raw;      // X, Y, Z, D65 at 1 nm (4 x 471)
@@ -738,11 +739,15 @@ struct HostScene {
         double min_world_radius = rs["min_world_radius"].as_double(10.0);
         const Json &spec = root["spectrum"];
         std::string spec_type = spec["type"].as_string("srgb");
-        if (opt.spectrum == 1) spec_type = "srgb"; else if (opt.spectrum == 2) spec_type = "hero";
+        if (opt.spectrum == 1) spec_type = "srgb"; else if (opt.spectrum == 2 || opt.spectrum == 3) spec_type = "hero";
         if (spec_type != "srgb" && spec_type != "hero") fail("spectrum/" + spec_type + " is outside the hot-path scope (srgb, hero)");
-        if (spec["param"]["dimension"].as_uint(3) != 3) fail("spectrum/" + spec_type + " with dimension != 3 is outside the hot-path scope (paths carry three wavelengths)");
+        spectrum_dimension = 3;
+        if (spec_type == "hero") { // HeroWavelengthSpectrum::dimension_ (hero.cpp:240); srgb.cpp is always 3
+            spectrum_dimension = opt.spectrum == 3 ? 4u : spec["param"]["dimension"].as_uint(3);
+            if (spectrum_dimension != 3 && spectrum_dimension != 4) fail("spectrum/hero with dimension " + std::to_string(spectrum_dimension) + " is outside the hot-path scope (megakernel instances exist for 3 and 4 wavelengths per path)");
+        }
         if (spec_type == "hero" && !list_only) init_hero();
-        describe("spectrum", spec_type, "");
+        describe("spectrum", spec_type, spectrum_dimension == 4 ? "dimension 4" : "");
         // mediums (scene_desc.cpp:26-35, MediumDesc::init node_desc.cpp:182-197, homogeneous.cpp:20-24)
         uint32_t global_medium = VMK_INVALID;
         params.process_mediums = 0; params.camera_medium = VMK_INVALID;
@@ -1121,6 +1126,7 @@ struct HostScene {
         scene.alias_prob = alias_prob.data(); scene.alias_idx = alias_idx.data(); scene.alias_func = alias_func.data();
         for (int k = 0; k < 3; ++k) { scene.world_min[k] = (float) bmin[k]; scene.world_max[k] = (float) bmax[k]; }
         scene.spectrum = hero ? VMK_SPECTRUM_HERO : VMK_SPECTRUM_SRGB;
+        scene.spectrum_dimension = spectrum_dimension;
         scene.rgb2spec = hero ? rgb2spec.data() : nullptr; scene.spd_data = hero ? spd.data() : nullptr; scene.n_spd = (uint32_t) spd.size();
         // sheen needs the LTC tables; without them only sheen_weight == 0 (constant) is accepted
         if (!scene.luts.sheen_approx)

@@ -90,7 +90,7 @@ class HostScene:
             L.vmk_host_clear_images()
         opt = _abi.HostOptions(width, height, max_depth, min_depth, int(procedural_env), int(drop_unsupported_lights),
                                (lut_path or DEFAULT_LUT_PATH).encode(), int(mediums),
-                               {None: 0, "srgb": 1, "hero": 2}[spectrum], {None: 0, "fail": 0, "standin": 1}[missing_assets])
+                               {None: 0, "srgb": 1, "hero": 2, "hero4": 3}[spectrum], {None: 0, "fail": 0, "standin": 1}[missing_assets])
         h = C.c_void_p()
         rc = L.vmk_host_load_scene(json_path.encode(), C.byref(opt), C.byref(h))
         if rc != 0 and decode == "native" and "vmk_host_register_image" in _err():  # a container the native decoders do not handle
