@@ -119,6 +119,7 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("cbox_hero4_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
     ("cbox_hero4_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4),
     ("glass_of_water_hero4", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
+    ("cbox_prism_hero4", "scenes/cbox/cbox-prism.json", 48, 48, 2),  # the reference's own "dimension": 4 scene as shipped (dispersive sphere, checker.jpg)
 ])
 def test_render_matches_oracle_and_golden(backend, name, scene, w, h, spp):
     hero = "hero" in name

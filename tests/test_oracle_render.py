@@ -32,7 +32,8 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          ("glass_of_water_hero", "scenes/glass-of-water/vision_scene.json", 48, 48, 2), ("classroom_hero", "scenes/classroom/vision_scene.json", 48, 27, 2),
          # spectrum/hero with "dimension": 4 (cbox-prism.json:692-697): four wavelengths per path — the vmk_hero4.hip instance / the ORC_SPEC_DIM = 4 oracle build
          ("cbox_hero4", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero4_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
-         ("cbox_hero4_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("glass_of_water_hero4", "scenes/glass-of-water/vision_scene.json", 48, 48, 2)]
+         ("cbox_hero4_media", "scenes/cbox/cbox_hero_media.json", 32, 32, 4), ("glass_of_water_hero4", "scenes/glass-of-water/vision_scene.json", 48, 48, 2),
+         ("cbox_prism_hero4", "scenes/cbox/cbox-prism.json", 48, 48, 2)]  # the reference's own dimension-4 scene, as shipped
 MEDIA = {"cbox_media", "classroom_fog", "cbox_hero_media", "cbox_hero4_media"}
 SPECTRUM = {"glass_of_water_hero": "hero", "classroom_hero": "hero",  # shipped scenes with the spectrum forced to hero (vmk_host_options.spectrum)
             "cbox_hero4": "hero4", "cbox_hero4_matte": "hero4", "cbox_hero4_media": "hero4", "glass_of_water_hero4": "hero4"}  # ... to hero with four wavelengths
