@@ -68,7 +68,10 @@ inline bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &o
             uint8_t lens[320];
             if (type == 1) {
                 int i = 0;
-                for (; i < 144; ++i) lens[i] = 8; for (; i < 256; ++i) lens[i] = 9; for (; i < 280; ++i) lens[i] = 7; for (; i < 288; ++i) lens[i] = 8;
+                for (; i < 144; ++i) lens[i] = 8;
+                for (; i < 256; ++i) lens[i] = 9;
+                for (; i < 280; ++i) lens[i] = 7;
+                for (; i < 288; ++i) lens[i] = 8;
                 hl.build(lens, 288);
                 for (i = 0; i < 30; ++i) lens[i] = 5;
                 hd.build(lens, 30);
