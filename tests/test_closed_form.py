@@ -168,7 +168,10 @@ PL_ALBEDO = np.array([0.6, 0.4, 0.2])
 PL_W, PL_HGT, PL_FOV = 32, 24, 50.0
 
 
-def _scene_point(tmp_path):
+SPOT_ANGLE, SPOT_FALLOFF = 35.0, 12.0    # degrees: cone half-angle and width of the smooth edge (spot.cpp:33-35,62-70)
+
+
+def _scene_point(tmp_path, spot=False):
     # the quad lies in its local xz plane: the plane y = -1.  It is shifted sideways so that the diagonal its two triangles share does not
     # run through pixel centres: the Moeller-Trumbore test of this build (and of the oracle) is not watertight the way OptiX is, and a
     # ray aimed exactly at a shared edge can miss both triangles (seen here with an unshifted quad: 1 of 1536 camera rays)
@@ -180,43 +183,68 @@ def _scene_point(tmp_path):
         "integrator": {"type": "pt", "param": {"max_depth": 1, "min_depth": 5, "rr_threshold": 1}},
         "camera": {"type": "thin_lens", "param": {"fov_y": PL_FOV, "lens_radius": 0.0, "transform": {"type": "look_at", "param": {"position": [0, 0, 0], "up": [0, 0, -1], "target_pos": [0, -1, 0]}},
                                                   "filter": {"type": "box", "param": {"radius": 0.001}}}},
-        "light_sampler": {"type": "uniform", "param": {"lights": [{"type": "point", "name": "bulb", "param": {"color": [3.0, 2.0, 1.0], "scale": 0.7, "position": [0.0, -1.0 + PL_H, 0.0]}}]}},
+        "light_sampler": {"type": "uniform", "param": {"lights": [
+            {"type": "spot", "name": "bulb", "param": {"color": [3.0, 2.0, 1.0], "scale": 0.7, "position": [0.0, -1.0 + PL_H, 0.0], "direction": [0, -1, 0], "angle": SPOT_ANGLE, "falloff": SPOT_FALLOFF}} if spot else
+            {"type": "point", "name": "bulb", "param": {"color": [3.0, 2.0, 1.0], "scale": 0.7, "position": [0.0, -1.0 + PL_H, 0.0]}}]}},
         "spectrum": {"type": "srgb"},
         "pipeline": {"type": "fixed", "param": {"frame_buffer": {"type": "normal", "param": {"resolution": [PL_W, PL_HGT], "exposure": 1, "tone_mapper": {"type": "linear"}}}}},
         "output": {"fn": "x.png", "spp": 1},
     }
-    path = os.path.join(str(tmp_path), "closed_point.json")
+    path = os.path.join(str(tmp_path), f"closed_point_{int(spot)}.json")
     json.dump(sc, open(path, "w"))
     return path
 
 
-def _expected_point():
+def _expected_point(spot=False):
     yy, xx = np.mgrid[0:PL_HGT, 0:PL_W]
     k = 2.0 * np.tan(np.radians(PL_FOV) / 2.0) / PL_HGT          # world units per pixel on the plane (camera height 1, square pixels)
     r2 = ((xx + 0.5 - PL_W / 2.0) * k) ** 2 + ((yy + 0.5 - PL_HGT / 2.0) * k) ** 2
     geo = PL_H / (r2 + PL_H ** 2) ** 1.5                           # cos(theta) / d^2
+    if spot:  # SpotLight::falloff: ((clamp(cos, cos_angle, cos_start) - cos_angle) / (cos_start - cos_angle))^4, cos = h / d on the axis
+        cos_l = PL_H / np.sqrt(r2 + PL_H ** 2)
+        # spot.cpp:33-35 as written: angle_ = radians(clamp(angle, 1, 89)); falloff_ = radians(clamp(falloff, 0, angle_)) — the upper
+        # bound of the second clamp is angle_ ALREADY IN RADIANS, so 12 (degrees) is clamped to 0.611 and the smooth edge is 0.61 degrees
+        # wide, not 12.  The drop-in reproduces the reference, not the intent.
+        angle = np.radians(np.clip(SPOT_ANGLE, 1.0, 89.0))
+        falloff = np.radians(np.clip(SPOT_FALLOFF, 0.0, angle))
+        ca, cs = np.cos(angle), np.cos(max(0.0, angle - falloff))
+        geo = geo * ((np.clip(cos_l, ca, cs) - ca) / (cs - ca)) ** 4
     return geo[..., None] * (PL_I * PL_ALBEDO / np.pi)[None, None, :]
 
 
-def _check_point(img, cnt):
+def _check_point(img, cnt, spot=False):
     rgb = img[..., :3].astype(np.float64)
-    exp = _expected_point()
-    err = np.abs(rgb / exp - 1.0).max()
+    exp = _expected_point(spot)
+    lit = exp[..., 0] > 1e-3 * exp[..., 0].max()
+    dark = exp[..., 0] == 0.0
+    if spot:  # the smooth edge is 0.61 degrees wide (see _expected_point) and a 4th power: leave the pixels inside it out of both sets
+        yy, xx = np.mgrid[0:PL_HGT, 0:PL_W]
+        k = 2.0 * np.tan(np.radians(PL_FOV) / 2.0) / PL_HGT
+        cos_l = PL_H / np.sqrt(((xx + 0.5 - PL_W / 2.0) * k) ** 2 + ((yy + 0.5 - PL_HGT / 2.0) * k) ** 2 + PL_H ** 2)
+        angle = np.radians(SPOT_ANGLE)
+        lit = cos_l > np.cos(angle - np.radians(angle)) + 2e-3
+        dark = cos_l < np.cos(angle) - 2e-3
+        assert lit.sum() > 60 and dark.sum() > 100  # the cone covers part of the picture
+    err = np.abs(rgb[lit] / exp[lit] - 1.0).max()
     # 2e-3: the sample sits within 0.001 px of the pixel centre (the geometric term changes by < 1e-3 over that), float32 elsewhere
-    assert err < 2e-3, (err, rgb[0, 0], exp[0, 0], rgb[PL_HGT // 2, PL_W // 2], exp[PL_HGT // 2, PL_W // 2])
-    assert cnt["shadow_rays"] == cnt["surface_hits"] == PL_W * PL_HGT * 2  # every camera ray hits the floor, every vertex casts one shadow ray
+    assert err < 2e-3, (err, rgb[PL_HGT // 2, PL_W // 2], exp[PL_HGT // 2, PL_W // 2])
+    assert (rgb[dark] == 0.0).all()  # outside the cone: exactly nothing
+    n_vertices = PL_W * PL_HGT * 2
+    assert cnt["shadow_rays"] == cnt["surface_hits"] == n_vertices  # every camera ray hits the floor, every vertex casts one shadow ray
 
 
-def test_point_light_over_a_plane_closed_form_oracle(built, tmp_path):
-    hs, img, cnt = _render_oracle(_scene_point(tmp_path), False, spp=2)
+@pytest.mark.parametrize("spot", [False, True])
+def test_point_light_over_a_plane_closed_form_oracle(built, tmp_path, spot):
+    hs, img, cnt = _render_oracle(_scene_point(tmp_path, spot), False, spp=2)
     assert hs.params.max_depth == 1 and hs.scene.n_lights == 1
-    _check_point(img, cnt)
+    _check_point(img, cnt, spot)
 
 
 @pytest.mark.gpu
-def test_point_light_over_a_plane_closed_form_gpu(built, tmp_path):
-    path = _scene_point(tmp_path)
+@pytest.mark.parametrize("spot", [False, True])
+def test_point_light_over_a_plane_closed_form_gpu(built, tmp_path, spot):
+    path = _scene_point(tmp_path, spot)
     hs, img, cnt = _render_gpu(path, False, spp=2)
-    _check_point(img, cnt)
+    _check_point(img, cnt, spot)
     _, ref, _ = _render_oracle(path, False, spp=2)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
