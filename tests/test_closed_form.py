@@ -19,6 +19,10 @@ something independent).  Each case is checked on the CPU oracle (always) and on 
    alias table (area.cpp:120-149, pdf converted from area to solid angle) plus the BSDF-sampled rays that reach the emitter, each
    with its MIS weight, must add up to Lambert's polygon formula   E(P) = Le / 2 * | sum_k theta_k (Gamma_k . n) |,
    L = albedo / pi * E   (theta_k: angle an edge subtends at P, Gamma_k: unit normal of the plane through P and the edge).
+6. A closed furnace: the camera inside a cube whose six walls all emit Le and reflect diffusely with albedo a.  Every vertex sees Le in
+   every direction, so the radiance is the geometric series  Le (1 + a + a^2 + ...) = Le / (1 - a)  whatever the geometry — provided the
+   throughput update, the MIS weights of the two ways to find an emitter (they must sum to 1), the light-selection pmf, the emission at
+   hit vertices and the Russian-roulette compensation (T / q) are all right.  max_depth 24 truncates the series at a^24 = 6e-8.
 """
 import json
 import os
@@ -321,3 +325,55 @@ def test_area_light_polygon_irradiance_closed_form_gpu(built, tmp_path):
     path = _scene_area(tmp_path)
     hs, img, cnt = _render_gpu(path, False, spp=512)
     _check_area(img)
+
+
+# ---- 6. closed furnace: geometric series ----
+FU_LE, FU_A = np.array([1.0, 0.7, 0.4]), 0.5
+
+
+def _scene_furnace(tmp_path, rr_threshold):
+    def wall(name, rows):
+        return {"type": "quad", "name": name, "param": {"width": 1.0, "height": 1.0, "material": "wall", "transform": {"type": "matrix4x4", "param": {"matrix4x4": rows}},
+                                                       "emission": {"type": "area", "param": {"color": [float(c) for c in FU_LE], "two_sided": True, "scale": 1.0}}}}
+    # rows = images of the quad's local x, y (its normal), z axes and the translation; every wall is a 2 x 2 square of the cube [-1, 1]^3
+    shapes = [wall("floor", [[2, 0, 0, 0], [0, 1, 0, 0], [0, 0, 2, 0], [0, -1, 0, 1]]), wall("ceil", [[2, 0, 0, 0], [0, 1, 0, 0], [0, 0, 2, 0], [0, 1, 0, 1]]),
+              wall("back", [[2, 0, 0, 0], [0, 0, 1, 0], [0, 2, 0, 0], [0, 0, -1, 1]]), wall("front", [[2, 0, 0, 0], [0, 0, 1, 0], [0, 2, 0, 0], [0, 0, 1, 1]]),
+              wall("left", [[0, 0, 2, 0], [1, 0, 0, 0], [0, 2, 0, 0], [-1, 0, 0, 1]]), wall("right", [[0, 0, 2, 0], [1, 0, 0, 0], [0, 2, 0, 0], [1, 0, 0, 1]])]
+    sc = {
+        "shapes": shapes,
+        "materials": [{"type": "diffuse", "name": "wall", "param": {"color": [FU_A, FU_A, FU_A]}}],
+        "sampler": {"type": "independent", "param": {"spp": 1}},
+        "integrator": {"type": "pt", "param": {"max_depth": 24, "min_depth": 3, "rr_threshold": rr_threshold}},
+        "camera": {"type": "thin_lens", "param": {"fov_y": 70, "transform": {"type": "look_at", "param": {"position": [0.1, -0.2, 0.3], "up": [0, 1, 0], "target_pos": [0.4, -0.5, -1]}},
+                                                  "filter": {"type": "box", "param": {"radius": 0.5}}}},
+        "light_sampler": {"type": "uniform", "param": {"lights": []}},
+        "spectrum": {"type": "srgb"},
+        "pipeline": {"type": "fixed", "param": {"frame_buffer": {"type": "normal", "param": {"resolution": [16, 12], "exposure": 1, "tone_mapper": {"type": "linear"}}}}},
+        "output": {"fn": "x.png", "spp": 1},
+    }
+    path = os.path.join(str(tmp_path), f"closed_furnace_{rr_threshold}.json")
+    json.dump(sc, open(path, "w"))
+    return path
+
+
+def _check_closed_furnace(img, cnt):
+    rgb = img[..., :3].astype(np.float64)
+    assert np.isfinite(rgb).all()
+    expected = FU_LE / (1.0 - FU_A)
+    mean = rgb.reshape(-1, 3).mean(0)
+    assert np.abs(mean / expected - 1.0).max() < 0.003, (mean, expected)                # 49k paths: the mean to 0.3 % (measured: 4e-4 with RR, 2e-5 without)
+    assert np.abs(rgb / expected - 1.0).max() < 0.10, np.abs(rgb / expected - 1.0).max()  # no pixel far off (256 spp each; measured 0.04)
+    assert cnt["closest_rays"] > 3 * cnt["paths"]  # paths really bounce (RR ends them at depth 4-8 on average, not at 1)
+
+
+@pytest.mark.parametrize("rr_threshold", [1.0, 0.0])  # with Russian roulette (T / q compensation) and without (all 24 bounces)
+def test_closed_furnace_geometric_series_oracle(built, tmp_path, rr_threshold):
+    hs, img, cnt = _render_oracle(_scene_furnace(tmp_path, rr_threshold), False, spp=256)
+    assert hs.scene.n_lights == 6 and hs.params.max_depth == 24
+    _check_closed_furnace(img, cnt)
+
+
+@pytest.mark.gpu
+def test_closed_furnace_geometric_series_gpu(built, tmp_path):
+    hs, img, cnt = _render_gpu(_scene_furnace(tmp_path, 1.0), False, spp=256)
+    _check_closed_furnace(img, cnt)
