@@ -373,7 +373,8 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
  * miss), MaterialEvaluator::albedo (material.cpp:91-98), emitted radiance (evaluate_hit_wi), each width*height
  * RGBA floats, linear depth = (world-to-camera * p).z (sensor.cpp:192-195), width*height floats, and the motion
  * vector p_film - prev_raster_coord(p) (frame_buffer.cpp:483-491, sensor.cpp:95-100; the previous camera is the
- * current one, so this is the lens / filter reprojection offset), width*height*2 floats.  Any output may be NULL. */
+ * current one, so this is the lens / filter reprojection offset), width*height*2 floats.  Any output may be NULL.
+ * spectrum/hero: albedo and emission are linear_srgb(spectrum, the pixel's wavelengths of this frame) (:169-170,192-203). */
 int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba,
                    float *depth, float *motion_xy);
 

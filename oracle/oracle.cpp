@@ -1483,9 +1483,12 @@ inline Spec lobe_albedo(const vmk_scene *s, const Lobe &l, float cos_theta) {
     }
 }
 struct PixelAov { float3 normal, albedo, emission; float depth; float2 motion; bool hit; };
+inline Swl *path_wavelengths(const vmk_scene *s, uint32_t x, uint32_t y, uint32_t frame, Swl &storage);
 inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const float *w2c, const float *s2r, uint32_t px, uint32_t py, uint32_t frame) {
     PixelAov a{make_float3(0.f), make_float3(0.f), make_float3(0.f), 0.f, make_float2(0.f, 0.f), false};
     const vmk_scene *s = sv.s;
+    Swl swl_store;
+    tl_swl = path_wavelengths(s, px, py, frame, swl_store); // RenderEnv::initial (frame_buffer.cpp:169-170); null for srgb
     Sampler sampler; sampler.start(px, py, frame, 0);
     float2 p_film;
     Ray ray = generate_ray(p, px, py, sampler, &p_film);
@@ -1504,14 +1507,16 @@ inline PixelAov primary_aov(SceneView &sv, const vmk_render_params &p, const flo
     if (it.has_material()) {
         LobeSet lobes; build_lobe_set(s, s->materials[it.mat_id], it, lobes);
         float cos_theta = dot(it.shading.z, it.wo);
-        // (the G-buffer pass exists for spectrum/srgb only, like the device's: the spectrum is the RGB triple)
-        if (!lobes.is_set) a.albedo = spec_as_rgb(lobe_albedo(s, lobes.lobes[0], cos_theta));
-        else for (int i = 0; i < lobes.n; ++i) a.albedo += spec_as_rgb(lobe_albedo(s, lobes.lobes[i], cos_theta) * lobes.lobes[i].weight);
+        // frame_buffer.cpp:192-196: linear_srgb(bsdf.albedo(wo), swl) — the lobe set's weighted sum as a spectrum, converted once
+        Spec sum = make_spec(0.f);
+        if (!lobes.is_set) sum = lobe_albedo(s, lobes.lobes[0], cos_theta);
+        else for (int i = 0; i < lobes.n; ++i) sum += lobe_albedo(s, lobes.lobes[i], cos_theta) * lobes.lobes[i].weight;
+        a.albedo = spec_linear_srgb(s, sum);
     }
     if (it.has_emission()) {
         LightCtx lc{s, &p};
         LightSampleContext p_ref{ray.o, ray.d};
-        a.emission = spec_as_rgb(light_evaluate_hit_wi(lc, p_ref, it).L);
+        a.emission = spec_linear_srgb(s, light_evaluate_hit_wi(lc, p_ref, it).L); // :197-203
     }
     return a;
 }

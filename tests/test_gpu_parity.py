@@ -264,8 +264,10 @@ def test_error_behaviour(backend):
         be.upload_scene(hs)
     hs.scene.spd_cie_count = keep
     be.upload_scene(hs)      # the untouched tables are accepted
-    with pytest.raises(BackendError, match="sRGB instance"):
-        be.build_accel(); be.set_render_params(hs.params_copy()); be.render_aov(0)
+    be.build_accel(); be.set_render_params(hs.params_copy())
+    assert np.isfinite(be.render_aov(0)["albedo"]).all()  # the G-buffer pass exists for every spectrum instance
+    with pytest.raises(BackendError, match="sRGB instance"):  # the ray capture and the material unit kernel do not
+        be.test_eval(7, np.zeros((1, 3), np.float32), 1 + 16 * 24)
     be.close()
 
 
@@ -329,10 +331,14 @@ def test_hip_albedo_precompute_matches_oracle_and_reference_tables(backend, whic
 
 
 @pytest.mark.parametrize("scene, w, h, kw", [("scenes/cbox/cbox_materials.json", 64, 64, {}), ("scenes/classroom/vision_scene.json", 96, 54, {}), ("scenes/cbox/cbox_sheen.json", 48, 48, {}), ("scenes/cbox/cbox_extra.json", 48, 48, {}),
-                                            ("scenes/cbox/cbox_lights.json", 40, 40, {}), ("scenes/cbox/cbox_normal.json", 48, 48, {})])
+                                            ("scenes/cbox/cbox_lights.json", 40, 40, {}), ("scenes/cbox/cbox_normal.json", 48, 48, {}),
+                                            # spectrum/hero: albedo and emission are spectra brought to linear sRGB through the pixel's wavelengths
+                                            ("scenes/cbox/cbox_hero.json", 48, 48, {}), ("scenes/cbox/cbox_hero.json", 48, 48, {"spectrum": "hero4"}),
+                                            ("scenes/cbox/cbox-prism.json", 40, 40, {}), ("scenes/classroom/vision_scene.json", 96, 54, {"spectrum": "hero"})])
 def test_aov_planes_match_oracle(backend, scene, w, h, kw):
     """vmk_render_aov (the reference's G-buffer kernel, frame_buffer.cpp:156-219): shading normal, linear depth, material
-    albedo (every lobe class incl. the LUT-based coat / specular albedos of principled_bsdf) and emission, bit for bit."""
+    albedo (every lobe class incl. the LUT-based coat / specular albedos of principled_bsdf) and emission, bit for bit — for all
+    three spectrum instances (sRGB; hero with three and four wavelengths: `linear_srgb(bsdf.albedo(wo), swl)`, :192-203)."""
     hs, p, osc, _ = _load(backend, scene, w, h, **kw)
     g = backend.render_aov(frame=2)
     o = osc.render_aov(p, frame=2)

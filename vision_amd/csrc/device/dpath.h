@@ -1130,9 +1130,8 @@ VD void mat_lobe(const DScene &S, const MatCtx &mc, const Interaction &it, int i
 }
 // MaterialEvaluator::albedo (material.cpp:91-98) = LobeSet::albedo (lobe.cpp:564-570) over the per-class Lobe::albedo
 // (bxdf.h:91,153; substrate.cpp:22; lobe.cpp:208-210,308-313; CoatLobe / SpecularLobe principled_bsdf.cpp:154-160,198-205);
-// used by the AOV pass only (frame_buffer.cpp:192-196), always instantiated with FULL = true.
-#if !VMK_HERO
-VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, bool principled_lobe, const Lobe &l, float cos_theta) {
+// used by the AOV pass only (frame_buffer.cpp:192-196: `linear_srgb(bsdf.albedo(wo), swl)`), always instantiated with FULL = true.
+VD Spec lobe_albedo(const DScene &S, const MatCtx &mc, int k, bool principled_lobe, const Lobe &l, float cos_theta) {
     switch (l.kind) {
         case LB_MICROFACET: {
             if (mc.is_set && principled_lobe && (k == 1 || k == 4)) {
@@ -1140,29 +1139,28 @@ VD V3 lobe_albedo(const DScene &S, const MatCtx &mc, int k, bool principled_lobe
                 if (k == 1) { float sv; sample_lut3d<1>(S.lut_coat, mk3(x, cos_theta, inverse_lerp(mc.cc_ior, 1.003f, 4.f)), &sv); return sv * l.kr; }
                 float z = sqrt_(abs_((mc.ior - 1.0f) / (mc.ior + 1.0f)));
                 float sv; sample_lut3d<1>(S.lut_specular, mk3(x, cos_theta, z), &sv);
-                return lerp3(sv, l.fr.a, mk3(1.f)) * l.kr;
+                return lerp3(sv, l.fr.a, mks(1.f)) * l.kr;
             }
             return l.kr * l.fr.evaluate(cos_theta);
         }
-        case LB_DIELECTRIC: { V3 F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; }
+        case LB_DIELECTRIC: { Spec F = l.fr.evaluate(abs_(cos_theta)); return l.kr * (1.f - F) + F; }
         case LB_PLASTIC: return l.fr.evaluate(cos_theta); // MicrofacetLobe::albedo with the specular bxdf's kr = 1 (plastic.cpp:119)
         default: return l.kr; // Lambert / Oren-Nayar / FresnelBlend Rd / sheen (albedo folded into kr at build time)
     }
 }
-VD V3 mat_albedo(const DScene &S, const MatCtx &mc, const Interaction &it, DCounters &cnt) {
+VD Spec mat_albedo(const DScene &S, const MatCtx &mc, const Interaction &it, DCounters &cnt SWL_P) {
     float cos_theta = dot(it.shading.z, it.wo);
     Lobe l;
-    if (!mc.is_set) { mat_lobe<true>(S, mc, it, 0, l, cnt); return lobe_albedo(S, mc, 0, false, l, cos_theta); }
-    V3 sum = mk3(0.f);
+    if (!mc.is_set) { mat_lobe<true>(S, mc, it, 0, l, cnt SWL_A); return lobe_albedo(S, mc, 0, false, l, cos_theta); }
+    Spec sum = mks(0.f);
     for (int i = 0; i < mc.n; ++i) {
-        mat_lobe<true>(S, mc, it, i, l, cnt);
+        mat_lobe<true>(S, mc, it, i, l, cnt SWL_A);
         bool pl = mc.m->type == VMK_MAT_PRINCIPLED; int ip = i;
         if (mc.pchild >= 0) { const int np = mc.n - 1; pl = mc.pchild == 0 ? i < np : i > 0; ip = mc.pchild == 0 ? i : i - 1; }
         sum += lobe_albedo(S, mc, pl ? ip + mc.first : 0, pl, l, cos_theta) * l.weight;
     }
     return sum;
 }
-#endif
 // Lobe::evaluate / LobeSet::evaluate_impl (lobe.cpp:53-75,673-688) in world space; all lobes share it.shading.
 // A single-lobe material is the n = 1 case of the same loop (its weights are 1, so the products are exact).
 template<bool FULL>

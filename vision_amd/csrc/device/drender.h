@@ -463,6 +463,74 @@ __global__ void k_unit_path(const DScene *scene, const vmk_render_params *P, uin
     unit_path(S, P, s_ws, s_us, live, f2u(a[0]), f2u(a[1]), f2u(a[2]), o, cnt);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// AOVs of the primary hit — FrameBuffer::compile_compute_geom, the `rt_geom` kernel (frame_buffer.cpp:156-219): shading normal,
+// linear depth, motion vector, MaterialEvaluator::albedo and the emitted radiance, the last two brought to linear sRGB through the
+// pixel's wavelengths when the spectrum is hero.  One thread per pixel; the primary rays go through the same wave-cooperative
+// traversal as the megakernel's.
+// ---------------------------------------------------------------------------------------------------------
+struct AovArgs {
+    const DScene *scene;
+    const vmk_render_params *params;
+    float4 *normal, *albedo, *emission; // RGBA planes or null
+    float *depth;
+    float2 *motion;
+    uint32_t frame;
+    float w2s[16]; // inverse(c2w)              (Sensor::store_prev_data sensor.cpp:89-93; the camera is static within a render)
+    float s2r[16]; // inverse(raster_to_sensor)
+};
+__global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
+    __shared__ WaveScratch s_ws[kBlock / 64];
+    const DScene S = *A.scene;
+    const vmk_render_params *P = A.params;
+    WaveScratch *ws = s_ws + (threadIdx.x >> 6);
+    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+    const uint32_t n = P->width * P->height;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) { // block-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t px = live ? i % P->width : 0u, py = live ? i / P->width : 0u;
+#if VMK_HERO
+        Sampler wl; wl.start(px, py, A.frame, 0xFFFFFFFFu); // RenderEnv::initial (frame_buffer.cpp:169-170): the pixel's wavelengths for this frame
+        const Swl swl = sample_wavelengths(wl);
+#endif
+        Sampler sampler; sampler.start(px, py, A.frame, 0);
+        V2 p_film;
+        Ray ray = generate_ray(P, px, py, sampler, &p_film);
+        Hit hit;
+        bool found = traverse_wave<true, true>(S, ray, live, false, ws, hit, cnt); // (DEEP: serves every tree)
+        if (!live) continue;
+        V3 normal = mk3(0.f), albedo = mk3(0.f), emission = mk3(0.f);
+        float depth = 0.f;
+        V2 motion = {0.f, 0.f};
+        if (found) {
+            Interaction it;
+            compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
+            it.wo = normalize(-ray.d);
+            normal = it.shading.z;
+            depth = A.w2s[2] * it.pos.x + A.w2s[6] * it.pos.y + A.w2s[10] * it.pos.z + A.w2s[14];
+            { // compute_motion_vec (frame_buffer.cpp:483-491) against Sensor::prev_raster_coord (sensor.cpp:95-100)
+                V3 ps = transform_point4(A.w2s, it.pos);
+                ps = ps / ps.z;
+                V3 rc = transform_point4(A.s2r, ps);
+                motion = {p_film.x - rc.x, p_film.y - rc.y};
+            }
+            if (it.mat_id != VMK_INVALID) {
+                MatCtx mc; // (the albedo of a lobe does not depend on its shading frame: no compute_shading_frame here)
+                mat_prepare<true>(S, S.materials + it.mat_id, it, mc, cnt SWL_A);
+                albedo = spec_linear_srgb(S, mat_albedo(S, mc, it, cnt SWL_A) SWL_A); // frame_buffer.cpp:192-196
+            }
+            if (it.light_id != VMK_INVALID) emission = spec_linear_srgb(S, light_evaluate_hit_wi(S, P, ray.o, it, cnt SWL_A).L SWL_A); // :197-203
+        }
+        if (A.normal) A.normal[i] = make_float4(normal.x, normal.y, normal.z, found ? 1.f : 0.f);
+        if (A.albedo) A.albedo[i] = make_float4(albedo.x, albedo.y, albedo.z, 1.f);
+        if (A.emission) A.emission[i] = make_float4(emission.x, emission.y, emission.z, 1.f);
+        if (A.depth) A.depth[i] = depth;
+        if (A.motion) A.motion[i] = make_float2(motion.x, motion.y);
+    }
+}
+
+
 // the twelve ahead-of-time variants: <FULL, MEDIA> x {tallying, not tallying} for trees that fit the LDS stack, and the tallying
 // <FULL, MEDIA> instances with the HBM stack overflow for deep trees
 typedef void (*RenderKernel)(RenderArgs);

@@ -29,7 +29,8 @@ using namespace vmkd;
 #define VMK_HERO_DECL(prefix) \
 hipError_t prefix##occupancy(bool full, bool media, bool count, bool deep, int *blocks_per_cu); \
 hipError_t prefix##launch_unit_path(hipStream_t stream, const void *scene, const void *params, uint32_t n, const float *in, uint32_t in_stride, float *out, uint32_t out_stride); \
-hipError_t prefix##launch_render(bool full, bool media, bool count, bool deep, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes);
+hipError_t prefix##launch_render(bool full, bool media, bool count, bool deep, unsigned blocks, hipStream_t stream, const void *rest, size_t rest_bytes, const void *scene, size_t scene_bytes); \
+hipError_t prefix##launch_aov(unsigned blocks, hipStream_t stream, const void *args, size_t args_bytes);
 VMK_HERO_DECL(vmk_hero_)
 VMK_HERO_DECL(vmk_hero4_)
 
@@ -406,67 +407,7 @@ __global__ void k_test(const DScene *scene, const vmk_render_params *P, uint32_t
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// AOV pass (FrameBuffer::compile_compute_geom, frame_buffer.cpp:156-219): the primary hit's shading normal, linear depth
-// (sensor.cpp:192-195), material albedo and emitted radiance for frame `frame` — what a denoiser is handed.  One lane per
-// pixel; the primary rays go through the same wave-cooperative traversal as the megakernel's.
-// ---------------------------------------------------------------------------------------------------------
-struct AovArgs {
-    const DScene *scene;
-    const vmk_render_params *params;
-    float4 *normal, *albedo, *emission; // RGBA planes or null
-    float *depth;
-    float2 *motion;
-    uint32_t frame;
-    float w2s[16]; // inverse(c2w)              (Sensor::store_prev_data sensor.cpp:89-93; the camera is static within a render)
-    float s2r[16]; // inverse(raster_to_sensor)
-};
-__global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
-    __shared__ WaveScratch s_ws[kBlock / 64];
-    const DScene S = *A.scene;
-    const vmk_render_params *P = A.params;
-    WaveScratch *ws = s_ws + (threadIdx.x >> 6);
-    DCounters cnt = {0, 0, 0, 0, 0, 0, 0};
-    const uint32_t n = P->width * P->height;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) { // block-uniform trip count
-        const uint32_t i = base + threadIdx.x;
-        const bool live = i < n;
-        const uint32_t px = live ? i % P->width : 0u, py = live ? i / P->width : 0u;
-        Sampler sampler; sampler.start(px, py, A.frame, 0);
-        V2 p_film;
-        Ray ray = generate_ray(P, px, py, sampler, &p_film);
-        Hit hit;
-        bool found = traverse_wave<true, true>(S, ray, live, false, ws, hit, cnt); // (DEEP: serves every tree)
-        if (!live) continue;
-        V3 normal = mk3(0.f), albedo = mk3(0.f), emission = mk3(0.f);
-        float depth = 0.f;
-        V2 motion = {0.f, 0.f};
-        if (found) {
-            Interaction it;
-            compute_surface_interaction<true>(S, hit.tri, hit.inst, hit.prim, hit.bary, it);
-            it.wo = normalize(-ray.d);
-            normal = it.shading.z;
-            depth = A.w2s[2] * it.pos.x + A.w2s[6] * it.pos.y + A.w2s[10] * it.pos.z + A.w2s[14];
-            { // compute_motion_vec (frame_buffer.cpp:483-491) against Sensor::prev_raster_coord (sensor.cpp:95-100)
-                V3 ps = transform_point4(A.w2s, it.pos);
-                ps = ps / ps.z;
-                V3 rc = transform_point4(A.s2r, ps);
-                motion = {p_film.x - rc.x, p_film.y - rc.y};
-            }
-            if (it.mat_id != VMK_INVALID) {
-                MatCtx mc; // (the albedo of a lobe does not depend on its shading frame: no compute_shading_frame here)
-                mat_prepare<true>(S, S.materials + it.mat_id, it, mc, cnt);
-                albedo = mat_albedo(S, mc, it, cnt);
-            }
-            if (it.light_id != VMK_INVALID) emission = light_evaluate_hit_wi(S, P, ray.o, it, cnt).L;
-        }
-        if (A.normal) A.normal[i] = make_float4(normal.x, normal.y, normal.z, found ? 1.f : 0.f);
-        if (A.albedo) A.albedo[i] = make_float4(albedo.x, albedo.y, albedo.z, 1.f);
-        if (A.emission) A.emission[i] = make_float4(emission.x, emission.y, emission.z, 1.f);
-        if (A.depth) A.depth[i] = depth;
-        if (A.motion) A.motion[i] = make_float2(motion.x, motion.y);
-    }
-}
+// (the AOV pass — AovArgs, k_aov — lives in drender.h: one instance per spectrum, like the megakernel)
 
 // ---------------------------------------------------------------------------------------------------------
 // Albedo-table precompute (the reference's `vision-precompute` app, apps/precompute/main.cpp:24-41):
@@ -1343,7 +1284,6 @@ static bool inverse4(const float *m, float *out) {
 int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albedo_rgba, float *emission_rgba, float *depth, float *motion_xy) {
     if (!ctx) return VMK_ERR_ARG;
     if (!ctx->accel_ready || !ctx->params_ready) { ctx->error = "vmk_render_aov: scene/accel/params not ready"; return VMK_ERR_STATE; }
-    if (ctx->hero) { ctx->error = "vmk_render_aov: the G-buffer kernel is the sRGB instance; a hero-spectrum scene is uploaded"; return VMK_ERR_UNSUPPORTED; }
     if (ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_render_aov: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n = (size_t) ctx->params.width * ctx->params.height;
@@ -1360,8 +1300,11 @@ int vmk_render_aov(vmk_ctx *ctx, uint32_t frame, float *normal_rgba, float *albe
     A.scene = ctx->d_scene.p; A.params = ctx->d_params.p; A.normal = dn.p; A.albedo = da.p; A.emission = de.p; A.depth = dd.p; A.motion = dm.p; A.frame = frame;
     if (!inverse4(ctx->params.c2w, A.w2s) || !inverse4(ctx->params.raster_to_sensor, A.s2r)) { cleanup(); ctx->error = "vmk_render_aov: camera matrix is singular"; return VMK_ERR_ARG; }
     uint32_t grid = (uint32_t) std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * 6);
-    hipLaunchKernelGGL(k_aov, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
-    e = hipGetLastError();
+    if (ctx->hero) e = (ctx->hero4 ? vmk_hero4_launch_aov : vmk_hero_launch_aov)(grid, ctx->stream, &A, sizeof(A)); // (same AovArgs layout in every instance)
+    else {
+        hipLaunchKernelGGL(k_aov, dim3(grid), dim3(kBlock), 0, ctx->stream, A);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess && normal_rgba) e = hipMemcpyAsync(normal_rgba, dn.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && albedo_rgba) e = hipMemcpyAsync(albedo_rgba, da.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && emission_rgba) e = hipMemcpyAsync(emission_rgba, de.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);

@@ -46,3 +46,12 @@ hipError_t HERO_FN(launch_unit_path)(hipStream_t stream, const void *scene, cons
     hipLaunchKernelGGL(k_unit_path, dim3((n + 63) / 64), dim3(64), 0, stream, (const DScene *) scene, (const vmk_render_params *) params, n, in, in_stride, out, out_stride);
     return hipGetLastError();
 }
+// the hero instance of the AOV pass (drender.h k_aov): albedo and emission come back as linear sRGB through the pixel's wavelengths
+hipError_t HERO_FN(launch_aov)(unsigned blocks, hipStream_t stream, const void *args, size_t args_bytes) {
+    using namespace vmkd;
+    AovArgs A;
+    if (args_bytes != sizeof(AovArgs)) return hipErrorInvalidValue;
+    std::memcpy(&A, args, sizeof(AovArgs));
+    hipLaunchKernelGGL(k_aov, dim3(blocks), dim3(kBlock), 0, stream, A);
+    return hipGetLastError();
+}
