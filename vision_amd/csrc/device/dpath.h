@@ -1200,7 +1200,7 @@ VD V3 mat_sample_wi(const DScene &S, const MatCtx &mc, const Interaction &it, Sa
         (void) sampler.next_2d();
         float sum_weights = 0.f;
         for (int i = 0; i < mc.n; ++i) {
-            float sw;
+            float sw = 0.f; // (always assigned below: a lobe set is a mix / add or a principled_bsdf)
             int ip = i; float parent = 1.f; bool principled = mc.m->type == VMK_MAT_PRINCIPLED;
             if (mc.m->type == VMK_MAT_MIX || mc.m->type == VMK_MAT_ADD) {
                 const int np = mc.pchild >= 0 ? mc.n - 1 : 0;
