@@ -39,6 +39,17 @@ def test_lint_flags_spill_code_in_front_of_the_exec_restore(tmp_path):
     assert func == "_Z1kv" and label == ".LBB0_5" and "offset:784" in text
 
 
+def test_hoisting_the_exec_restore_repairs_the_block(tmp_path):
+    p = os.path.join(str(tmp_path), "bad.s")
+    open(p, "w").write(BAD)
+    assert isa_lint.hoist_exec_restores(p) == 1 and isa_lint.lint(p) == []
+    text = open(p).read()
+    assert text.index("s_or_b64 exec, exec, s[14:15]") < text.index("s_mov_b32 s36") < text.index("scratch_store_dword off, v78")
+    for clean in (GOOD, TAIL):  # nothing to do: files stay as they are
+        open(p, "w").write(clean)
+        assert isa_lint.hoist_exec_restores(p) == 0 and open(p).read() == clean
+
+
 def test_the_library_that_ships_passed_the_lint(built):
     """build() compiles with -save-temps, lints the gfx950 assembly of the three translation units and refuses a library with a
     site; the stamp records the result for the sources and flags the library was built from."""

@@ -58,6 +58,32 @@ def lint(path):
     return found
 
 
+def hoist_exec_restores(path):
+    """Repair: in every join block the lint flags, move the `s_or_b64 exec, exec, ...` to the top of the block.  Whatever sits between a
+    join label and its EXEC restore was put there by passes that assume the join's lanes (the restore itself is emitted first in the
+    block by SILowerControlFlow; its operand is computed before the branch), so running the restore first is what the compiler meant.
+    Returns the number of blocks changed; the file is rewritten in place."""
+    lines = open(path, errors="replace").read().split("\n")
+    join_targets = {m.group(1) for l in lines for m in [BRANCH_T.search(l)] if m}
+    changed = 0
+    i = 0
+    while i < len(lines):
+        m = LABEL.match(lines[i])
+        if m and m.group(1) in join_targets:
+            j = i + 1
+            spill = False
+            while j < len(lines) and not LABEL.match(lines[j]) and not ANY_BRANCH.match(lines[j]) and not EXEC_RESTORE.match(lines[j]):
+                spill = spill or bool(SPILL.match(lines[j]))
+                j += 1
+            if spill and j < len(lines) and EXEC_RESTORE.match(lines[j]):
+                lines.insert(i + 1, lines.pop(j))
+                changed += 1
+        i += 1
+    if changed:
+        open(path, "w").write("\n".join(lines))
+    return changed
+
+
 if __name__ == "__main__":
     bad = 0
     for p in sys.argv[1:]:
