@@ -168,13 +168,20 @@ def test_config1_cbox_1024x1024_matches_oracle_on_sampled_tiles(backend):
     ("scenes/glass-of-water/vision_scene.json", 1024, 1024, 2, {}),            # config 4 "spectral glass" at its resolution
     # BASELINE config 4 exactly as worded: 1024x1024, spectrum hero, max depth 64 (+ min depth 3) — the divergence stress
     ("scenes/glass-of-water/vision_scene.json", 1024, 1024, 2, {"max_depth": 64, "min_depth": 3}),
+    # the four-wavelength instance (vmk_hero4.hip) at full size: classroom at the headline resolution, config 4 at depth 64, and the
+    # reference's own dimension-4 scene at the 1024^2 its JSON asks for
+    ("scenes/classroom/vision_scene.json", 1920, 1080, 2, {"spectrum": "hero4"}),
+    ("scenes/glass-of-water/vision_scene.json", 1024, 1024, 2, {"max_depth": 64, "min_depth": 3, "spectrum": "hero4"}),
+    ("scenes/cbox/cbox-prism.json", 1024, 1024, 2, {"spectrum": None}),
 ])
 def test_hero_full_size_matches_oracle_on_sampled_tiles(backend, scene, w, h, frames, kw):
-    """The hero-spectrum instance of the megakernel (vmk_hero.hip) at full size: vmk_self_check against its unit-kernel twin,
-    then the GPU renders the whole image, the oracle every 64th 32x32 tile, bit for bit."""
+    """The hero-spectrum instances of the megakernel (vmk_hero.hip, vmk_hero4.hip) at full size: vmk_self_check against the unit-kernel
+    twin, then the GPU renders the whole image, the oracle every 64th 32x32 tile, bit for bit."""
     from vision_amd import _abi
-    hs, p, osc, _ = _load(backend, scene, w, h, spectrum="hero", **kw)
-    assert hs.scene.spectrum == 1
+    kw = dict(kw)
+    spectrum = kw.pop("spectrum", "hero")
+    hs, p, osc, _ = _load(backend, scene, w, h, spectrum=spectrum, **kw)
+    assert hs.scene.spectrum == 1 and hs.scene.spectrum_dimension == (3 if spectrum == "hero" else 4)
     assert backend.self_check() > 4000
     backend.reset_accum(); backend.reset_counters()
     backend.render_batch(0, frames)
