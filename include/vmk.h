@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VMK_ABI_VERSION 6u
+#define VMK_ABI_VERSION 7u
 #define VMK_INVALID 0xFFFFFFFFu
 
 typedef enum vmk_status {
@@ -87,7 +87,10 @@ enum { /* principled slot indices, principled_bsdf.cpp:235-256 */
 /* A material / light parameter slot (ShaderNodeSlot, src/base/shader_graph/shader_node.cpp:242-273).
  * tex == VMK_INVALID : constant, value v[0..2] (scalar slots use v[0]).
  * otherwise          : image node (render_core/shadernode/image.cpp:87-97): texel(uv) * v[0](=scale),
- *                      low 16 bits = texture index, bits 16..21 = 3 x 2-bit channel swizzle (x,y,z sources). */
+ *                      low 16 bits = texture index, bits 16..21 = 3 x 2-bit channel swizzle (x,y,z sources).
+ *                      bit 22 (VMK_SLOT_TINTED): a "multiply" node of that image with a constant (render_core/shadernode/math.cpp:34-92,
+ *                      BinaryOpNode): swizzle(texel(uv)) * (v[0], v[1], v[2]) per channel; the image's own scale is 1 then. */
+#define VMK_SLOT_TINTED (1u << 22)
 typedef struct vmk_slot {
     float v[3];
     uint32_t tex;

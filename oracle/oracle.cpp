@@ -154,9 +154,13 @@ inline void sample_lut3d(const float *lut, int nc, float3 uvw, float *out) {
 inline float3 eval_slot3(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
     if (sl.tex == VMK_INVALID) return {sl.v[0], sl.v[1], sl.v[2]};
     float4 t = sample_image(s, sl.tex & 0xffffu, uv);
-    float c[4] = {t.x * sl.v[0], t.y * sl.v[0], t.z * sl.v[0], t.w * sl.v[0]};
+    const bool tinted = (sl.tex & VMK_SLOT_TINTED) != 0u; // "multiply" node: image x constant (math.cpp:78-90, BinaryOpNode always multiplies)
+    const float scale = tinted ? 1.f : sl.v[0];
+    float c[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
     uint32_t sw = sl.tex >> 16;
-    return {c[sw & 3u], c[(sw >> 2) & 3u], c[(sw >> 4) & 3u]};
+    float3 r = {c[sw & 3u], c[(sw >> 2) & 3u], c[(sw >> 4) & 3u]};
+    if (tinted) r = r * make_float3(sl.v[0], sl.v[1], sl.v[2]);
+    return r;
 }
 inline float eval_slot1(const vmk_scene *s, const vmk_slot &sl, float2 uv) {
     if (sl.tex == VMK_INVALID) return sl.v[0];

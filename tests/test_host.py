@@ -258,6 +258,51 @@ def test_hero_dimension_4_wavelengths_closed_form_and_round_trip(built, tmp_path
     assert not oracle_py.lib(3).orc_scene_create(C.cast(hs.tables, C.c_void_p))
 
 
+def test_multiply_shader_node(built, tmp_path):
+    """render_core/shadernode/math.cpp (BinaryOpNode: every binary node multiplies): constant x constant is folded by the host in
+    float32, image x constant travels as a tinted image slot (VMK_SLOT_TINTED); two images, an image scale other than 1 and a multiply
+    in a normal slot are refused.  Multiplying by (1, 1, 1) must not change a single bit of the picture."""
+    import json
+    from oracle import oracle_py
+    text = open(os.path.join(ROOT, "scenes", "cbox", "cbox_materials.json")).read()
+    base = json.loads("\n".join(l for l in text.split("\n") if not l.lstrip().startswith("//")))
+    import shutil; shutil.copy(os.path.join(ROOT, "scenes/cbox/checker.png"), str(tmp_path))
+    tex_mat = next(m for m in base["materials"] if isinstance(m["param"].get("color"), dict) and "checker.png" in json.dumps(m["param"]["color"]))
+    img_slot = tex_mat["param"]["color"]
+
+    def variant(color, name):
+        sc = json.loads(json.dumps(base))
+        next(m for m in sc["materials"] if m["name"] == tex_mat["name"])["param"]["color"] = color
+        path = os.path.join(str(tmp_path), name + ".json"); json.dump(sc, open(path, "w"))
+        return path
+
+    def mul(lhs, rhs, channels="xyz"):
+        return {"channels": channels, "node": {"type": "multiply", "param": {"lhs": lhs, "rhs": rhs}}}
+    num = lambda v: {"channels": "xyz", "node": {"type": "number", "param": {"value": v}}}
+    plain = HostScene(variant(img_slot, "plain"), width=24, height=24)
+    ident = HostScene(variant(mul(img_slot, num([1, 1, 1])), "ident"), width=24, height=24)
+    tint = HostScene(variant(mul(num([0.9, 1.0, 0.5]), img_slot), "tint"), width=24, height=24)   # constant on the left works too
+    mid = [m["name"] for m in base["materials"]].index(tex_mat["name"])
+    s_plain, s_ident, s_tint = (h.scene.materials[mid].slot[0] for h in (plain, ident, tint))
+    assert not (s_plain.tex & _abi.SLOT_TINTED) and (s_ident.tex & _abi.SLOT_TINTED) and (s_tint.tex & _abi.SLOT_TINTED)
+    assert (s_ident.tex & 0x3FFFFF) == (s_plain.tex & 0x3FFFFF) and list(s_tint.v) == pytest.approx([0.9, 1.0, 0.5])
+    img = {k: oracle_py.OracleScene(h).render(h.params_copy(), 0, 2)[0] for k, h in (("plain", plain), ("ident", ident), ("tint", tint))}
+    assert np.array_equal(img["plain"].view(np.uint32), img["ident"].view(np.uint32))       # x * 1.0 is exact
+    assert not np.array_equal(img["plain"], img["tint"]) and img["tint"][..., 2].sum() < img["plain"][..., 2].sum()
+    # constant x constant folds to the product (float32)
+    const = HostScene(variant(mul(num([0.5, 0.25, 2.0]), num([0.5, 2.0, 0.25]), "zyx"), "const"), width=24, height=24)
+    sc = const.scene.materials[mid].slot[0]
+    assert sc.tex == _abi.INVALID and list(sc.v) == [0.5, 0.5, 0.25]                                # (z, y, x) of (0.25, 0.5, 0.5)
+    for bad, msg in ((mul(img_slot, img_slot), "two images"),
+                     (mul({"channels": "xyz", "node": {"type": "image", "param": {"fn": "checker.png", "color_space": "srgb", "scale": 2.0}}}, num([1, 1, 1])), "scale other than 1"),
+                     (mul(mul(img_slot, num([1, 1, 1])), num([1, 1, 1])), "nested multiply")):
+        with pytest.raises(HostError, match=msg):
+            HostScene(variant(bad, "bad"), width=24, height=24)
+    # the reference's playground scene carries one such node and loads as shipped
+    pg = HostScene(os.path.join(ROOT, "scenes/playground/vision_scene.json"), width=32, height=32)
+    assert sum(1 for i in range(pg.scene.n_materials) for j in range(18) if pg.scene.materials[i].slot[j].tex not in (_abi.INVALID, 0xFFFFFFFD) and pg.scene.materials[i].slot[j].tex & _abi.SLOT_TINTED) == 1
+
+
 def test_bathroom2_loads_with_declared_standins(built):
     """BASELINE config 5's scene: the reference checkout lacks 10 meshes, WoodPanel.png and the HDRI.  Without the option the
     loader fails on the first missing asset; with vmk_host_options.missing_assets = standin every substitution is listed."""

@@ -24,7 +24,9 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          ("cbox_sheen", "scenes/cbox/cbox_sheen.json", 32, 32, 4),  # principled_bsdf with its sheen (LTC) layer
          ("cbox_extra", "scenes/cbox/cbox_extra.json", 32, 32, 4),
          # Material::compute_shading_frame with "normal" slots, mix / add with a principled_bsdf child (LobeSet::flatten), shape/sphere
-         ("cbox_normal", "scenes/cbox/cbox_normal.json", 32, 32, 4),  # material/metallic and material/add
+         ("cbox_normal", "scenes/cbox/cbox_normal.json", 32, 32, 4),
+         # the reference's playground scene as shipped: a "multiply" shader node (checker.jpg x a constant), a normal map, mix, principled
+         ("playground", "scenes/playground/vision_scene.json", 48, 48, 2),  # material/metallic and material/add
          # spectrum/hero: all material families incl. dispersive BK7 + measured Cu; diffuse only; media; point + spot
          # lights; config 4 as worded ("spectral glass"); classroom with its environment map and image textures
          ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),

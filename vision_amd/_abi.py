@@ -1,7 +1,8 @@
 """ctypes mirror of include/vmk.h and include/vmk_host.h (plain C structs, no torch types)."""
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
+SLOT_TINTED = 1 << 22  # vmk_slot.tex: image x constant ("multiply" shader node)
 SLOT_SPD = 0xFFFFFFFD
 SPECTRUM_SRGB, SPECTRUM_HERO = 0, 1
 RGB2SPEC_RES = 64

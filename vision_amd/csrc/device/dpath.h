@@ -151,10 +151,14 @@ VD void sample_lut3d(const float *lut, V3 uvw, float *out) {
 VD V3 eval_slot3(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt) {
     if (sl.tex == VMK_INVALID) return {sl.v[0], sl.v[1], sl.v[2]};
     V4 t = sample_image(S, sl.tex & 0xffffu, uv, cnt);
-    float c[4] = {t.x * sl.v[0], t.y * sl.v[0], t.z * sl.v[0], t.w * sl.v[0]};
+    const bool tinted = (sl.tex & VMK_SLOT_TINTED) != 0u; // image x constant ("multiply" node, math.cpp:78-90)
+    const float scale = tinted ? 1.f : sl.v[0];
+    float c[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
     uint32_t sw = sl.tex >> 16;
     auto pick = [&](uint32_t k) { return k == 0 ? c[0] : (k == 1 ? c[1] : (k == 2 ? c[2] : c[3])); };
-    return {pick(sw & 3u), pick((sw >> 2) & 3u), pick((sw >> 4) & 3u)};
+    V3 r = {pick(sw & 3u), pick((sw >> 2) & 3u), pick((sw >> 4) & 3u)};
+    if (tinted) r = r * V3{sl.v[0], sl.v[1], sl.v[2]};
+    return r;
 }
 VD float eval_slot1(const DScene &S, const vmk_slot &sl, V2 uv, DCounters &cnt) {
     if (sl.tex == VMK_INVALID) return sl.v[0];

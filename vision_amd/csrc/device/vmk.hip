@@ -685,7 +685,7 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
     for (uint32_t i = 0; i < sc->n_materials; ++i) {
         const vmk_material &m = sc->materials[i];
         if (m.type > VMK_MAT_PLASTIC) { ctx->error = "vmk_upload_scene: unknown material type"; return VMK_ERR_ARG; }
-        if ((m.flags & VMK_MATF_HAS_NORMAL) && (m.normal.tex == VMK_SLOT_SPD || !slot_ok(m.normal) || m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD)) { ctx->error = "vmk_upload_scene: bad normal slot"; return VMK_ERR_ARG; }
+        if ((m.flags & VMK_MATF_HAS_NORMAL) && (m.normal.tex == VMK_SLOT_SPD || !slot_ok(m.normal) || (m.normal.tex != VMK_INVALID && (m.normal.tex & VMK_SLOT_TINTED)) || m.type == VMK_MAT_MIX || m.type == VMK_MAT_ADD)) { ctx->error = "vmk_upload_scene: bad normal slot"; return VMK_ERR_ARG; }
         for (int k = 0; k < VMK_MAX_SLOTS; ++k) {
             const vmk_slot &s = m.slot[k];
             const bool spd_allowed = (m.type == VMK_MAT_METAL && k < 2) || (m.type == VMK_MAT_GLASS && k == 1);

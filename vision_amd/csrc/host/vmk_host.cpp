@@ -412,8 +412,11 @@ struct HostScene {
         return sw;
     }
     vmk_slot parse_slot(const Json &param, const std::string &key, int dim, std::vector<float> def, bool env_image = false) {
+        return parse_slot_json(param[key], key, dim, def, env_image);
+    }
+    // a slot description: a bare value / array, {"channels", "node"}, or a node object (number / constant / image / multiply)
+    vmk_slot parse_slot_json(const Json &ps, const std::string &key, int dim, std::vector<float> def, bool env_image = false) {
         vmk_slot sl{}; sl.tex = VMK_INVALID;
-        const Json &ps = param[key];
         std::string channels = dim == 1 ? "x" : "xyz";
         const Json *node = &ps;
         if (ps.is_object() && ps.contains("channels")) { channels = ps["channels"].as_string(channels); node = &ps["node"]; }
@@ -429,7 +432,8 @@ struct HostScene {
             else { type = (*node)["type"].as_string(); p = &(*node)["param"]; }
             if (type == "image") { is_image = true; fn = (*p)["fn"].as_string(); color_space = (*p)["color_space"].as_string(); tex_scale = (*p)["scale"].as_float(1.f); }
             else if (type == "number" || type == "constant") { const Json &v = (*p)["value"]; if (!v.is_null()) value = v.as_float_vector(); }
-            else fail("shader node type '" + type + "' (slot '" + key + "') is outside the hot-path scope (number/constant/image only)");
+            else if (type == "multiply") return parse_multiply(*p, key, channels, dim, env_image);
+            else fail("shader node type '" + type + "' (slot '" + key + "') is outside the hot-path scope (number / constant / image / multiply of an image and a constant)");
         }
         if (is_image) {
             uint32_t id = obtain_texture(fn, color_space, env_image);
@@ -445,6 +449,34 @@ struct HostScene {
         sl.v[0] = c[sw & 3u]; sl.v[1] = dim == 1 ? 0.f : c[(sw >> 2) & 3u]; sl.v[2] = dim == 1 ? 0.f : c[(sw >> 4) & 3u];
         return sl;
     }
+    // "multiply" (render_core/shadernode/math.cpp:34-92: BinaryOpNode — its `op_` is never set, so every binary node multiplies):
+    // lhs * rhs per channel, then the outer slot's channel selection.  Encoded for constant x constant (folded here, in float32 like the
+    // kernel would) and image x constant (VMK_SLOT_TINTED: the constant rides in the slot's v[0..2]); the image's own "scale" must be 1
+    // for the latter (the slot has no room for both, and (t * s) * c is not t * (s * c) in float32).
+    vmk_slot parse_multiply(const Json &p, const std::string &key, const std::string &channels, int dim, bool env_image) {
+        vmk_slot l = parse_slot_json(p["lhs"], key + ".lhs", 3, {1.f, 1.f, 1.f}, env_image);
+        vmk_slot r = parse_slot_json(p["rhs"], key + ".rhs", 3, {1.f, 1.f, 1.f}, env_image);
+        const bool li = l.tex != VMK_INVALID, ri = r.tex != VMK_INVALID;
+        if (li && ri) fail("slot '" + key + "': a multiply node of two images is outside the hot-path scope (image x constant, constant x constant)");
+        if ((li && (l.tex & VMK_SLOT_TINTED)) || (ri && (r.tex & VMK_SLOT_TINTED))) fail("slot '" + key + "': nested multiply nodes over an image are outside the hot-path scope");
+        const uint32_t sw = channel_mask(channels, dim); // output channel k reads operand channel (sw >> 2k) & 3
+        const int n_out = dim == 1 ? 1 : 3;
+        vmk_slot out{}; out.tex = VMK_INVALID;
+        uint32_t tex_sw = 0;
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t j = k < n_out ? (sw >> (2 * k)) & 3u : 0u;
+            if (k < n_out && j > 2u) fail("slot '" + key + "': channel 'w' of a multiply node is outside the hot-path scope");
+            if (!li && !ri) out.v[k] = k < n_out ? l.v[j] * r.v[j] : 0.f;
+            else {
+                const vmk_slot &img = li ? l : r, &c = li ? r : l;
+                if (img.v[0] != 1.f) fail("slot '" + key + "': an image with a scale other than 1 inside a multiply node is outside the hot-path scope");
+                out.v[k] = k < n_out ? c.v[j] : 0.f;
+                tex_sw |= (((img.tex >> 16) >> (2 * j)) & 3u) << (2 * k);
+            }
+        }
+        if (li || ri) out.tex = ((li ? l.tex : r.tex) & 0xffffu) | (tex_sw << 16) | VMK_SLOT_TINTED;
+        return out;
+    }
 
     // ---- materials (Scene::load_materials scene.cpp:111-118; initialize_slots of each plugin) ----
     uint32_t add_material(const Json &desc) {
@@ -458,6 +490,7 @@ struct HostScene {
         if (p.contains("normal")) { // Material::initialize_slots material.cpp:312-316: VS_INIT_SLOT_NO_DEFAULT(normal, Number)
             if (type == "mix" || type == "add") fail("material '" + name + "': a normal slot on mix / add has no effect in the reference (only its children build lobes) and is not accepted");
             m.normal = parse_slot(p, "normal", 3, {0.f, 0.f, 1.f});
+            if (m.normal.tex != VMK_INVALID && (m.normal.tex & VMK_SLOT_TINTED)) fail("material '" + name + "': a multiply node in the normal slot is outside the hot-path scope");
             m.flags |= VMK_MATF_HAS_NORMAL;
         }
         bool remap = p["remapping_roughness"].as_bool(true);
