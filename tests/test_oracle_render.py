@@ -26,7 +26,9 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          # Material::compute_shading_frame with "normal" slots, mix / add with a principled_bsdf child (LobeSet::flatten), shape/sphere
          ("cbox_normal", "scenes/cbox/cbox_normal.json", 32, 32, 4),
          # the reference's playground scene as shipped: a "multiply" shader node (checker.jpg x a constant), a normal map, mix, principled
-         ("playground", "scenes/playground/vision_scene.json", 48, 48, 2),  # material/metallic and material/add
+         ("playground", "scenes/playground/vision_scene.json", 48, 48, 2),
+         # a complete shipped scene (no stripped asset): 19 meshes, 13 lights, 3 JPG textures, 21 materials
+         ("staircase2", "scenes/staircase2/vision_scene.json", 48, 27, 2),  # material/metallic and material/add
          # spectrum/hero: all material families incl. dispersive BK7 + measured Cu; diffuse only; media; point + spot
          # lights; config 4 as worded ("spectral glass"); classroom with its environment map and image textures
          ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),
