@@ -120,7 +120,8 @@ typedef enum vmk_light_type {
     VMK_LIGHT_AREA = 0,     /* "area"      render_core/light/area.cpp */
     VMK_LIGHT_SPHERICAL = 1, /* "spherical" render_core/light/environments/spherical.cpp */
     VMK_LIGHT_POINT = 2,    /* "point"     render_core/light/point.cpp:19-48; IPointLight light.h:222-251, light.cpp:49-58 */
-    VMK_LIGHT_SPOT = 3      /* "spot"      render_core/light/spot.cpp:19-80 */
+    VMK_LIGHT_SPOT = 3,     /* "spot"      render_core/light/spot.cpp:19-80 */
+    VMK_LIGHT_PROJECTOR = 4 /* "projector" render_core/light/projector.cpp:31-111: a point light whose colour is an image seen through a frustum */
 } vmk_light_type;
 
 typedef struct vmk_light {
@@ -141,6 +142,9 @@ typedef struct vmk_light {
     float direction[3];    /* spot: normalised axis */
     float cos_angle;       /* spot: cos(angle), angle clamped to [1, 89] degrees (spot.cpp:30) */
     float cos_falloff_start; /* spot: cos(max(0, angle - falloff)) (spot.cpp:57-59) */
+    float w2o4[16];        /* projector: inverse(o2w_) as Projector::Le evaluates it per sample (projector.cpp:100), column-major 4x4;
+                            * position[] = o2w_[3].xyz */
+    float tan_xy[2];       /* projector: (ratio * tan(angle_y), tan(angle_y)), angle clamped to [1, 89] degrees (:41-47,104-106) */
 } vmk_light;
 
 /* ---- geometry -------------------------------------------------------------------------------- */

@@ -1377,6 +1377,19 @@ inline LightSample env_sample_wi(const vmk_scene *s, const vmk_light &l, const L
 inline LightSample point_sample_wi(const vmk_scene *s, const vmk_light &l, const LightSampleContext &p_ref) {
     LightSample ls;
     float3 pos = ld3(l.position);
+    if (l.type == VMK_LIGHT_PROJECTOR) { // Projector::Le projector.cpp:98-110
+        float3 p = transform_point4(l.w2o4, p_ref.pos);
+        float d2 = length_squared(p);
+        bool valid = p.z > 0.f;
+        p = p / p.z;
+        float2 tan_xy = make_float2(l.tan_xy[0], l.tan_xy[1]);
+        float2 uv = make_float2((p.x + tan_xy.x) / (2.f * tan_xy.x), (p.y + tan_xy.y) / (2.f * tan_xy.y));
+        valid = valid && uv.x >= 0.f && uv.x <= 1.f && uv.y >= 0.f && uv.y <= 1.f;
+        ls.eval.L = valid ? ((1.f * eval_slot_illumination(s, l.color, uv)) / d2) * l.scale : make_spec(0.f); // select(valid, 1, 0) * colour / d2 * scale
+        ls.eval.pdf = -1.f;
+        ls.p_light = pos;
+        return ls;
+    }
     float3 w_un = p_ref.pos - pos;
     Spec value = eval_slot_illumination(s, l.color, make_float2(0.f, 0.f)) * l.scale;
     if (l.type == VMK_LIGHT_SPOT) {

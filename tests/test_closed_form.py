@@ -179,7 +179,10 @@ PL_W, PL_HGT, PL_FOV = 32, 24, 50.0
 SPOT_ANGLE, SPOT_FALLOFF = 35.0, 12.0    # degrees: cone half-angle and width of the smooth edge (spot.cpp:33-35,62-70)
 
 
-def _scene_point(tmp_path, spot=False):
+PROJ_ANGLE = 30.0                        # degrees: half-angle of the projector's square frustum (ratio 1)
+
+
+def _scene_point(tmp_path, spot=False, projector=False):
     # the quad lies in its local xz plane: the plane y = -1.  It is shifted sideways so that the diagonal its two triangles share does not
     # run through pixel centres: the Moeller-Trumbore test of this build (and of the oracle) is not watertight the way OptiX is, and a
     # ray aimed exactly at a shared edge can miss both triangles (seen here with an unshifted quad: 1 of 1536 camera rays)
@@ -192,13 +195,15 @@ def _scene_point(tmp_path, spot=False):
         "camera": {"type": "thin_lens", "param": {"fov_y": PL_FOV, "lens_radius": 0.0, "transform": {"type": "look_at", "param": {"position": [0, 0, 0], "up": [0, 0, -1], "target_pos": [0, -1, 0]}},
                                                   "filter": {"type": "box", "param": {"radius": 0.001}}}},
         "light_sampler": {"type": "uniform", "param": {"lights": [
+            {"type": "projector", "name": "bulb", "param": {"color": [3.0, 2.0, 1.0], "scale": 0.7, "angle": PROJ_ANGLE, "ratio": 1.0,
+                                                          "o2w": {"type": "look_at", "param": {"position": [0.0, -1.0 + PL_H, 0.0], "up": [0, 0, -1], "target_pos": [0, -1, 0]}}}} if projector else
             {"type": "spot", "name": "bulb", "param": {"color": [3.0, 2.0, 1.0], "scale": 0.7, "position": [0.0, -1.0 + PL_H, 0.0], "direction": [0, -1, 0], "angle": SPOT_ANGLE, "falloff": SPOT_FALLOFF}} if spot else
             {"type": "point", "name": "bulb", "param": {"color": [3.0, 2.0, 1.0], "scale": 0.7, "position": [0.0, -1.0 + PL_H, 0.0]}}]}},
         "spectrum": {"type": "srgb"},
         "pipeline": {"type": "fixed", "param": {"frame_buffer": {"type": "normal", "param": {"resolution": [PL_W, PL_HGT], "exposure": 1, "tone_mapper": {"type": "linear"}}}}},
         "output": {"fn": "x.png", "spp": 1},
     }
-    path = os.path.join(str(tmp_path), f"closed_point_{int(spot)}.json")
+    path = os.path.join(str(tmp_path), f"closed_point_{int(spot)}_{int(projector)}.json")
     json.dump(sc, open(path, "w"))
     return path
 
@@ -412,4 +417,36 @@ def test_closed_furnace_with_a_conservative_medium_gpu(built, tmp_path):
     hs, img, cnt = _render_gpu(path, True, spp=256)
     _check_medium_furnace(img, cnt)
     _, ref, _ = _render_oracle(path, True, spp=256)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+# ---- 4b. projector light: a point light behind a square frustum (projector.cpp:98-110) ----
+def _check_projector(img, cnt):
+    """Constant colour: inside the frustum the point-light closed form, outside exactly nothing.  The frustum's footprint on the floor is
+    the square |x|, |z| <= h tan(angle) under the light (ratio 1: no axis convention involved)."""
+    rgb = img[..., :3].astype(np.float64)
+    exp = _expected_point(False)
+    yy, xx = np.mgrid[0:PL_HGT, 0:PL_W]
+    k = 2.0 * np.tan(np.radians(PL_FOV) / 2.0) / PL_HGT
+    ax, az = np.abs((xx + 0.5 - PL_W / 2.0) * k), np.abs((yy + 0.5 - PL_HGT / 2.0) * k)
+    half = PL_H * np.tan(np.radians(PROJ_ANGLE))
+    inside = (ax < half - 2 * k * 1e-3) & (az < half - 2 * k * 1e-3)
+    outside = (ax > half + 2 * k * 1e-3) | (az > half + 2 * k * 1e-3)
+    assert inside.sum() > 40 and outside.sum() > 300 and (inside | outside).all()
+    assert np.abs(rgb[inside] / exp[inside] - 1.0).max() < 2e-3
+    assert (rgb[outside] == 0.0).all()
+
+
+def test_projector_light_over_a_plane_closed_form_oracle(built, tmp_path):
+    hs, img, cnt = _render_oracle(_scene_point(tmp_path, projector=True), False, spp=2)
+    assert hs.scene.n_lights == 1 and hs.scene.lights[0].type == 4
+    _check_projector(img, cnt)
+
+
+@pytest.mark.gpu
+def test_projector_light_over_a_plane_closed_form_gpu(built, tmp_path):
+    path = _scene_point(tmp_path, projector=True)
+    hs, img, cnt = _render_gpu(path, False, spp=2)
+    _check_projector(img, cnt)
+    _, ref, _ = _render_oracle(path, False, spp=2)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))

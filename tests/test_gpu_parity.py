@@ -109,6 +109,7 @@ def test_traversal_hits_match_oracle(backend, scene, w, h):
     ("cbox_normal", "scenes/cbox/cbox_normal.json", 32, 32, 4),         # normal-mapped shading frames, mix/add of principled + single lobe, shape/sphere
     ("playground", "scenes/playground/vision_scene.json", 48, 48, 2),   # the reference's playground scene: "multiply" node (image x constant), normal map, mix, principled
     ("staircase2", "scenes/staircase2/vision_scene.json", 48, 27, 2),   # a complete shipped scene: 19 meshes, 13 area lights, JPG textures
+    ("cbox_vision_scene", "scenes/cbox/vision_scene.json", 48, 48, 2),  # the reference's default Cornell scene: spot, point, spherical, projector and area lights
     # spectrum/hero (§8f-2): the vmk_hero.hip instance of the megakernel, all four <FULL, MEDIA> variants
     ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4),             # every material family, dispersive BK7 glass, measured Cu, texture
     ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4), # single-lobe variant

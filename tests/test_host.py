@@ -103,7 +103,7 @@ def test_json_comments_and_defaults(built, tmp_path):
     (lambda s: s["integrator"].update(type="rt"), "integrator/rt"),
     (lambda s: s["spectrum"].update(type="hero", param={"dimension": 5}), "dimension 5"),
     (lambda s: s["spectrum"].update(type="rgb"), "spectrum/rgb"),
-    (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "projector", "param": {}}), "light/projector"),
+    (lambda s: s["light_sampler"]["param"]["lights"].append({"type": "ies", "param": {}}), "light/ies"),
     (lambda s: s["camera"]["param"].update(filter={"type": "blackman", "param": {"radius": 1}}), "filter/blackman"),
     (lambda s: s["shapes"].append({"type": "torus", "name": "s", "param": {}}), "shape/torus"),
     (lambda s: s["shapes"][-1]["param"].pop("emission"), "no light"),

@@ -28,7 +28,9 @@ CASES = [("cbox_matte", "scenes/cbox/cbox_matte.json", 32, 32, 8), ("cbox_materi
          # the reference's playground scene as shipped: a "multiply" shader node (checker.jpg x a constant), a normal map, mix, principled
          ("playground", "scenes/playground/vision_scene.json", 48, 48, 2),
          # a complete shipped scene (no stripped asset): 19 meshes, 13 lights, 3 JPG textures, 21 materials
-         ("staircase2", "scenes/staircase2/vision_scene.json", 48, 27, 2),  # material/metallic and material/add
+         ("staircase2", "scenes/staircase2/vision_scene.json", 48, 27, 2),
+         # the reference's default Cornell scene as shipped: spot + point + spherical + projector (Painting3.jpg) + area light in one scene
+         ("cbox_vision_scene", "scenes/cbox/vision_scene.json", 48, 48, 2),  # material/metallic and material/add
          # spectrum/hero: all material families incl. dispersive BK7 + measured Cu; diffuse only; media; point + spot
          # lights; config 4 as worded ("spectral glass"); classroom with its environment map and image textures
          ("cbox_hero", "scenes/cbox/cbox_hero.json", 32, 32, 4), ("cbox_hero_matte", "scenes/cbox/cbox_hero_matte.json", 32, 32, 4),

@@ -26,7 +26,8 @@ class Light(C.Structure):
     _fields_ = [("type", u32), ("inst_id", u32), ("two_sided", u32), ("scale", f32), ("color", Slot),
                 ("alias_offset", u32), ("alias_count", u32), ("alias_integral", f32), ("cond_offset", u32),
                 ("res_x", u32), ("res_y", u32), ("w2o", f32 * 9), ("o2w", f32 * 9), ("world_diameter", f32),
-                ("position", f32 * 3), ("direction", f32 * 3), ("cos_angle", f32), ("cos_falloff_start", f32)]
+                ("position", f32 * 3), ("direction", f32 * 3), ("cos_angle", f32), ("cos_falloff_start", f32),
+                ("w2o4", f32 * 16), ("tan_xy", f32 * 2)]
 
 
 class TriPos(C.Structure):

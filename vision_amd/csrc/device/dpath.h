@@ -1384,6 +1384,20 @@ VD LightSample env_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, V2 u
 VD LightSample point_sample_wi(const DScene &S, const vmk_light *l, V3 p_ref, DCounters &cnt SWL_P) {
     LightSample ls;
     V3 pos = ld3(l->position);
+    if (l->type == VMK_LIGHT_PROJECTOR) { // Projector::Le (projector.cpp:98-110): the image seen through the light's frustum, over d^2
+        V3 p = transform_point4(l->w2o4, p_ref);
+        const float d2 = length_squared(p);
+        bool valid = p.z > 0.f;
+        p = p / p.z;
+        const V2 tan_xy = {l->tan_xy[0], l->tan_xy[1]};
+        const V2 uv = {(p.x + tan_xy.x) / (2.f * tan_xy.x), (p.y + tan_xy.y) / (2.f * tan_xy.y)};
+        valid = valid && uv.x >= 0.f && uv.x <= 1.f && uv.y >= 0.f && uv.y <= 1.f;
+        // (outside the frustum the reference multiplies the fetched colour by 0; the fetch itself is skipped here: uv may be anything)
+        ls.eval.L = valid ? ((1.f * eval_slot_illumination(S, l->color, uv, cnt SWL_A)) / d2) * l->scale : mks(0.f);
+        ls.eval.pdf = -1.f;
+        ls.p_light = pos;
+        return ls;
+    }
     V3 w_un = p_ref - pos;
     Spec value = eval_slot_illumination(S, l->color, V2{0.f, 0.f}, cnt SWL_A) * l->scale;
     if (l->type == VMK_LIGHT_SPOT) {

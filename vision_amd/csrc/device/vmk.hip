@@ -715,6 +715,8 @@ int vmk_upload_scene(vmk_ctx *ctx, const vmk_scene *sc) {
             if (l.res_x == 0 || l.res_y == 0 || l.alias_count != l.res_y || (uint64_t) l.alias_offset + l.alias_count > sc->n_alias || (uint64_t) l.cond_offset + (uint64_t) l.res_x * l.res_y > sc->n_alias) { ctx->error = "vmk_upload_scene: environment light tables inconsistent"; return VMK_ERR_ARG; }
         } else if (l.type == VMK_LIGHT_POINT || l.type == VMK_LIGHT_SPOT) {
             if (l.type == VMK_LIGHT_SPOT && !(l.cos_falloff_start > l.cos_angle)) { ctx->error = "vmk_upload_scene: spot light cone is empty"; return VMK_ERR_ARG; }
+        } else if (l.type == VMK_LIGHT_PROJECTOR) {
+            if (!(l.tan_xy[0] > 0.f) || !(l.tan_xy[1] > 0.f) || (l.color.tex != VMK_INVALID && (l.color.tex & VMK_SLOT_TINTED))) { ctx->error = "vmk_upload_scene: projector light frustum / image slot invalid"; return VMK_ERR_ARG; }
         } else { ctx->error = "vmk_upload_scene: unknown light type"; return VMK_ERR_ARG; }
     }
     if (sc->light_alias_offset != VMK_INVALID && (uint64_t) sc->light_alias_offset + sc->n_lights > sc->n_alias) { ctx->error = "vmk_upload_scene: light-sampler alias table out of range"; return VMK_ERR_ARG; }

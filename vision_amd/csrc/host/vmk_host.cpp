@@ -862,11 +862,33 @@ struct HostScene {
                 }
                 pending.push_back({l, 0});
                 describe("light", type, ld["name"].as_string());
+            } else if (type == "projector") { // projector.cpp:31-49
+                vmk_light l{}; l.type = VMK_LIGHT_PROJECTOR; l.inst_id = VMK_INVALID;
+                init_light_color(l, p, false);
+                if (l.color.tex != VMK_INVALID && (l.color.tex & VMK_SLOT_TINTED)) fail("light/projector: a multiply node as the projected image is outside the hot-path scope");
+                const float deg = 3.14159265358979323846f / 180.f;
+                const float angle_y = std::min(89.f, std::max(1.f, p["angle"].as_float(45.f))) * deg;
+                float ratio = p["ratio"].as_float(1.f);
+                if (ratio == 0.f) { // the image's aspect ratio (:45-48)
+                    if (l.color.tex == VMK_INVALID) fail("light/projector: ratio 0 needs an image colour");
+                    const vmk_texture &t = textures[l.color.tex & 0xffffu];
+                    ratio = (float) t.width / (float) t.height;
+                }
+                const float tan_y = std::tan(angle_y); // (the reference evaluates tan(*angle_y_) per sample on the device: ocarina's tan, unpinned, App. B)
+                l.tan_xy[0] = ratio * tan_y; l.tan_xy[1] = tan_y;
+                Mat4 o2w = parse_transform(p["o2w"]);
+                Mat4 o2w_f{}; for (int i = 0; i < 16; ++i) o2w_f.m[i] = (double) (float) o2w.m[i]; // o2w_ is stored as float4x4; inverse(*o2w_) per sample (:100)
+                Mat4 w2o = inverse(o2w_f);
+                for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) l.w2o4[c * 4 + r] = (float) w2o.at(r, c);
+                for (int k = 0; k < 3; ++k) l.position[k] = (float) o2w_f.at(k, 3);                           // position() = o2w_[3].xyz (:91)
+                for (int k = 0; k < 3; ++k) l.direction[k] = (float) o2w_f.at(k, 2);                          // direction() = transform_vector(o2w_, (0, 0, 1)) (:95-97)
+                pending.push_back({l, 0});
+                describe("light", type, ld["name"].as_string());
             } else if (type == "area") {
                 fail("stand-alone light/area (own quad geometry, area.cpp:56-71) is outside the hot-path scope; use shape.param.emission");
             } else {
                 if (opt.drop_unsupported_lights) { describe("light", type, "DROPPED (outside hot-path scope)"); continue; }
-                fail("light/" + type + " is outside the hot-path scope (area, spherical, point, spot)");
+                fail("light/" + type + " is outside the hot-path scope (area, spherical, point, spot, projector)");
             }
         }
 
@@ -940,7 +962,7 @@ struct HostScene {
                 if (areas.empty()) fail("emissive shape without triangles");
                 AliasBuild a = build_alias(areas);
                 l.alias_offset = append_alias(a); l.alias_count = (uint32_t) areas.size(); l.alias_integral = a.integral;
-            } else if (l.type == VMK_LIGHT_POINT || l.type == VMK_LIGHT_SPOT) {
+            } else if (l.type == VMK_LIGHT_POINT || l.type == VMK_LIGHT_SPOT || l.type == VMK_LIGHT_PROJECTOR) {
                 // delta lights carry no tables
             } else { // SphericalMap::prepare (spherical.cpp:198-212) + AliasTable2D::build (alias2d.cpp:32-68)
                 scene.env_light = light_id;
@@ -996,7 +1018,16 @@ struct HostScene {
                 } else if (l.type == VMK_LIGHT_SPHERICAL) { // spherical.cpp:56-59; weighs nothing when sampled separately
                     f = params.env_separate ? 0.f : pi * (l.world_diameter / 2.f) * (l.world_diameter / 2.f);
                 } else if (l.type == VMK_LIGHT_POINT) f = 4.f * pi; // point.cpp:33-35
-                else { // spot.cpp:48-50 (angles in radians)
+                else if (l.type == VMK_LIGHT_PROJECTOR) { // projector.cpp:59-89: twice the solid angle of a spherical triangle over 4 pi
+                    const float ratio = l.tan_xy[0] / l.tan_xy[1];
+                    const float y = std::sqrt(1.f / (ratio * ratio + 1.f)), x = ratio * y, z = std::sqrt(x * x + y * y);
+                    auto cr = [](const float *a, const float *b, float *o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; float n = o[0] * o[0] + o[1] * o[1] + o[2] * o[2]; if (n > 0.f) { n = std::sqrt(n); o[0] /= n; o[1] /= n; o[2] /= n; } };
+                    const float p0[3] = {x, y, z}, p1[3] = {x, -y, z}, p2[3] = {-x, -y, z};
+                    float c01[3], c12[3], c20[3]; cr(p0, p1, c01); cr(p1, p2, c12); cr(p2, p0, c20);
+                    auto ang = [](const float *a, const float *b) { float d = -(a[0] * b[0] + a[1] * b[1] + a[2] * b[2]); return std::acos(std::min(1.f, std::max(-1.f, d))); };
+                    const float solid = std::fabs(ang(c01, c12) + ang(c12, c20) + ang(c20, c01) - pi);
+                    f = (2.f * solid) / (4.f * pi);
+                } else { // spot.cpp:48-50 (angles in radians)
                     float angle = std::acos(l.cos_angle), start = std::acos(l.cos_falloff_start);
                     f = 2.f * pi * (1.f - .5f * (angle * 2.f + (angle - start)));
                 }
