@@ -75,12 +75,21 @@ VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, V3 d, float *t_out, float *u_
 // The node stores each slab as a (min, max) pair so that both planes of a slab go through one v_pk_add_f32 + one
 // v_pk_mul_f32 (gfx950 packed fp32).  Measured and rejected: t = fma(b, inv, -o*inv) is not conservative for rays that
 // start on a box face (every bounce ray does): its absolute error |o*inv|*2^-24 is unbounded relative to (b-o)*inv.
+// The test is padded by 1e-4 relative on both ends.
 VD bool hit_box(f2v bx, f2v by, f2v bz, V3 o, V3 inv, float t_far, float *t_near_out) {
     f2v tx = (bx - o.x) * inv.x, ty = (by - o.y) * inv.y, tz = (bz - o.z) * inv.z;
     float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), 0.f));
     float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fminf(__builtin_fmaxf(tz.x, tz.y), t_far));
     *t_near_out = tn;
-    return tn * 0.999999f <= tf * 1.000001f;
+    // The margin also decides whether a leaf whose triangle computes a t slightly OUTSIDE its own box (ill-conditioned Moeller-Trumbore,
+    // typically two triangles meeting at an edge) is still visited once the culling bound has tightened to a near-equal hit: with 1e-6
+    // that depended on when the bound tightened — on the wave's scheduling — and two runs of the headline launch differed in about one
+    // path per 5e8; with 1e-4 four runs of 5.3e8 paths each agree in every bit (tools/gpu_determinism.py), at no measurable cost.
+#ifndef VMK_CULL_LO
+#define VMK_CULL_LO 0.9999f
+#define VMK_CULL_HI 1.0001f
+#endif
+    return tn * VMK_CULL_LO <= tf * VMK_CULL_HI;
 }
 
 VD void wave_lds_fence() { // LDS written by other lanes of this wave is visible after this point
