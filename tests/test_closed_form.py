@@ -336,7 +336,7 @@ def test_area_light_polygon_irradiance_closed_form_gpu(built, tmp_path):
 FU_LE, FU_A = np.array([1.0, 0.7, 0.4]), 0.5
 
 
-def _scene_furnace(tmp_path, rr_threshold, medium=False):
+def _scene_furnace(tmp_path, rr_threshold, medium=False, ball=None):
     def wall(name, rows):
         return {"type": "quad", "name": name, "param": {"width": 1.0, "height": 1.0, "material": "wall", "transform": {"type": "matrix4x4", "param": {"matrix4x4": rows}},
                                                        "emission": {"type": "area", "param": {"color": [float(c) for c in FU_LE], "two_sided": True, "scale": 1.0}}}}
@@ -356,10 +356,17 @@ def _scene_furnace(tmp_path, rr_threshold, medium=False):
         "pipeline": {"type": "fixed", "param": {"frame_buffer": {"type": "normal", "param": {"resolution": [16, 12], "exposure": 1, "tone_mapper": {"type": "linear"}}}}},
         "output": {"fn": "x.png", "spp": 1},
     }
+    if ball is not None:  # white-furnace test of one material: black walls that only emit (L = Le everywhere), a sphere of `ball` in view
+        sc["materials"][0]["param"]["color"] = [0.0, 0.0, 0.0]
+        sc["materials"].append(dict(ball, name="ball"))
+        sc["shapes"].append({"type": "sphere", "name": "ball", "param": {"radius": 0.35, "sub_div": 40, "material": "ball",
+                             "transform": {"type": "matrix4x4", "param": {"matrix4x4": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0.32, -0.42, -0.45, 1]]}}}})
+        sc["integrator"]["param"].update(max_depth=16, min_depth=16)
+        sc["pipeline"]["param"]["frame_buffer"]["param"]["resolution"] = [24, 18]
     if medium:  # a conservative (sigma_a = 0) scattering medium fills the cube: a uniform radiance field is invariant under it
         sc["mediums"] = {"global": "haze", "process": True, "list": [{"type": "homogeneous", "name": "haze", "param": {"g": 0.4, "scale": 1.0, "sigma_a": [0, 0, 0], "sigma_s": [0.9, 0.6, 0.3]}}]}
         sc["integrator"]["param"]["max_depth"] = 96  # scattering events count as bounces: ~3 per wall hit
-    path = os.path.join(str(tmp_path), f"closed_furnace_{rr_threshold}_{int(medium)}.json")
+    path = os.path.join(str(tmp_path), f"closed_furnace_{rr_threshold}_{int(medium)}_{ball['type'] if ball else 'none'}.json")
     json.dump(sc, open(path, "w"))
     return path
 
@@ -450,3 +457,40 @@ def test_projector_light_over_a_plane_closed_form_gpu(built, tmp_path):
     _check_projector(img, cnt)
     _, ref, _ = _render_oracle(path, False, spp=2)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+# ---- 7. white-furnace tests of the energy-compensated lobes ----
+# Inside walls that only emit (albedo 0), radiance is Le in every direction.  A lossless material in that field is invisible: every
+# pixel still reads Le.  glass (rough dielectric, colour 1) divides by its precomputed directional albedo so that this holds
+# (lobe.cpp:263-285), diffuse with colour 1 is the trivial case: both pin GGX D / G / VNDF sampling, the Fresnel branches, the
+# reflection / transmission choice and the albedo tables against physics rather than against the oracle.
+# mirror is meant to work the same way (lobe.cpp:716-729) but does NOT in the reference: PureReflectionLobe::compensate_factor looks its
+# table up at `alpha` where the table's axis is sqrt(alpha) (MicrofacetLobe::to_ratio_x, lobe.cpp:191-196, which the dielectric /
+# specular / coat lookups use), so a rough mirror is under-compensated — about 5 % dark at roughness 0.4.  The drop-in reproduces the
+# reference; the test records the loss (and would notice if it changed).
+WHITE = [
+    ({"type": "diffuse", "param": {"color": [1, 1, 1]}}, (0.996, 1.004)),
+    ({"type": "glass", "param": {"color": [1, 1, 1], "ior": 1.5, "roughness": 0.3}}, (0.985, 1.015)),
+    ({"type": "mirror", "param": {"color": [1, 1, 1], "roughness": 0.4}}, (0.975, 0.992)),   # whole picture; the sphere itself reads ~0.94
+]
+
+
+def _check_white_furnace(img, band):
+    rgb = img[..., :3].astype(np.float64)
+    assert np.isfinite(rgb).all()
+    ratio = rgb.reshape(-1, 3).mean(0) / FU_LE
+    assert band[0] < ratio.min() and ratio.max() < band[1], ratio
+    return ratio
+
+
+@pytest.mark.parametrize("ball, band", WHITE)
+def test_white_furnace_oracle(built, tmp_path, ball, band):
+    hs, img, cnt = _render_oracle(_scene_furnace(tmp_path, 0.0, ball=ball), False, spp=256)
+    assert cnt["closest_rays"] > 1.3 * cnt["paths"]  # the sphere is in view: paths bounce off it
+    _check_white_furnace(img, band)
+
+
+@pytest.mark.gpu
+def test_white_furnace_glass_gpu(built, tmp_path):
+    hs, img, cnt = _render_gpu(_scene_furnace(tmp_path, 0.0, ball=WHITE[1][0]), False, spp=256)
+    _check_white_furnace(img, WHITE[1][1])
