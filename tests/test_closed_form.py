@@ -494,3 +494,64 @@ def test_white_furnace_oracle(built, tmp_path, ball, band):
 def test_white_furnace_glass_gpu(built, tmp_path):
     hs, img, cnt = _render_gpu(_scene_furnace(tmp_path, 0.0, ball=WHITE[1][0]), False, spp=256)
     _check_white_furnace(img, WHITE[1][1])
+
+
+# ---- 8. pixel filters: an emissive half-plane seen through box / triangle / gaussian filters ----
+# The path tracer draws the film position from the filter (weight 1 in pipeline/fixed; sampler.h:65-73, fitted_curve.h:76-98), so a
+# pixel whose centre is t pixels left of a black / white edge reads   Le * P(offset > t) = Le * (1 - CDF_filter(t)).
+# box and triangle have closed-form CDFs; the gaussian (gaussian.cpp: max(0, g(x) - g(r)), sampled from a 20 x 20 table of it) is
+# compared with the CDF of that function, tolerance 0.015 for the table's piecewise-constant cells.
+def _scene_edge(tmp_path, filt):
+    path = _scene_point(tmp_path)
+    sc = json.load(open(path))
+    sc["light_sampler"]["param"]["lights"] = []
+    sc["materials"] = [{"type": "diffuse", "name": "black", "param": {"color": [0, 0, 0]}}]
+    big = 200.0  # the emissive half-plane x > 0 of the floor level (nothing on the other side: those rays leave the scene)
+    sc["shapes"] = [{"type": "quad", "name": "lamp", "param": {"width": 1.0, "height": 1.0, "material": "black",
+                     "transform": {"type": "matrix4x4", "param": {"matrix4x4": [[big, 0, 0, 0], [0, 1, 0, 0], [0, 0, big, 0], [big / 2, -1, 0.013 * big, 1]]}},
+                     "emission": {"type": "area", "param": {"color": [1.0, 0.5, 0.25], "two_sided": True, "scale": 2.0}}}}]
+    sc["camera"]["param"]["filter"] = filt
+    path = os.path.join(str(tmp_path), f"closed_edge_{filt['type']}.json")
+    json.dump(sc, open(path, "w"))
+    return path
+
+
+def _filter_cdf(filt, t):
+    r = float(np.atleast_1d(filt["param"]["radius"])[0])
+    t = np.clip(t, -r, r)
+    if filt["type"] == "box":
+        return (t + r) / (2 * r)
+    if filt["type"] == "triangle":
+        return 0.5 + t / r - np.sign(t) * t * t / (2 * r * r)
+    sigma = filt["param"]["sigma"]
+    x = np.linspace(-r, r, 400001)
+    g = lambda v: np.exp(-v * v / (2 * sigma * sigma)) / np.sqrt(2 * np.pi * sigma * sigma)
+    f = np.maximum(0.0, g(x) - g(r))
+    c = np.cumsum(f); c /= c[-1]
+    return np.interp(t, x, c)
+
+
+FILTERS = [({"type": "box", "param": {"radius": [1.5, 1.5]}}, 0.01), ({"type": "triangle", "param": {"radius": [2.0, 2.0]}}, 0.01),
+           ({"type": "gaussian", "param": {"radius": [2.0, 2.0], "sigma": 0.7}}, 0.015)]
+
+
+def _check_edge(img, filt, tol):
+    rgb = img[..., :3].astype(np.float64)
+    col = rgb.mean(0)[:, 0] / 2.0                                  # Le.r = 1.0 * 2.0; every row sees the same edge
+    t = PL_W / 2.0 - (np.arange(PL_W) + 0.5)                      # pixels from the column's centre to the edge (image x runs with world x)
+    want = 1.0 - _filter_cdf(filt, t)
+    assert np.abs(col - want).max() < tol, (filt["type"], np.abs(col - want).max(), col[PL_W // 2 - 3:PL_W // 2 + 3], want[PL_W // 2 - 3:PL_W // 2 + 3])
+    assert np.allclose(rgb[..., 1], rgb[..., 0] * 0.5, rtol=1e-6) and np.allclose(rgb[..., 2], rgb[..., 0] * 0.25, rtol=1e-6)
+
+
+@pytest.mark.parametrize("filt, tol", FILTERS)
+def test_pixel_filter_edge_response_oracle(built, tmp_path, filt, tol):
+    hs, img, cnt = _render_oracle(_scene_edge(tmp_path, filt), False, spp=2048)
+    _check_edge(img, filt, tol)
+
+
+@pytest.mark.gpu
+def test_pixel_filter_edge_response_gpu(built, tmp_path):
+    filt, tol = FILTERS[2]
+    hs, img, cnt = _render_gpu(_scene_edge(tmp_path, filt), False, spp=2048)
+    _check_edge(img, filt, tol)
