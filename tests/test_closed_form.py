@@ -555,3 +555,68 @@ def test_pixel_filter_edge_response_gpu(built, tmp_path):
     filt, tol = FILTERS[2]
     hs, img, cnt = _render_gpu(_scene_edge(tmp_path, filt), False, spp=2048)
     _check_edge(img, filt, tol)
+
+
+# ---- 9. a NON-uniform environment map: irradiance of a horizontal plane from the picture's own rows ----
+# spherical.cpp:60-125 + alias2d.cpp: the map is importance-sampled through a 2-D alias table, the pdf converted with 1 / (2 pi^2 sin
+# theta), BSDF-sampled rays that escape pick the map up with their MIS weight.  For a map that depends on the polar angle only and is
+# symmetric about the equator (so that neither the azimuth origin, nor flip_u, nor which pole is "up" enters), a diffuse floor under it reads
+#     L = albedo / pi * E,   E = 2 pi * integral_0^{pi/2} L_map(theta) cos(theta) sin(theta) d theta,
+# with L_map taken from the picture's rows (v = theta / pi, bilinear between row centres, 8-bit sRGB decoded) — computed here in numpy.
+def _env_rows(h):
+    v = (np.arange(h) + 0.5) / h
+    return 0.1 + 0.9 * np.cos(np.pi * v) ** 4            # bright poles, dim horizon; symmetric in v <-> 1 - v
+
+
+def _scene_envmap(tmp_path):
+    from PIL import Image
+    w, h = 64, 32
+    lin = _env_rows(h)
+    srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * lin ** (1 / 2.4) - 0.055)
+    px = np.clip(np.round(srgb * 255), 0, 255).astype(np.uint8)
+    Image.fromarray(np.repeat(px[:, None, None], w, 1).repeat(3, 2), "RGB").save(os.path.join(str(tmp_path), "bands.png"))
+    path = _scene(tmp_path, None, plane=True, max_depth=1)
+    sc = json.load(open(path))
+    sc["light_sampler"]["param"]["lights"] = [{"type": "spherical", "param": {"color": {"channels": "xyz", "node": {"type": "image", "param": {"fn": "bands.png", "color_space": "srgb"}}},
+                                                                             "scale": 1.5, "o2w": {"type": "Euler", "param": {"yaw": 35}}}}]
+    path = os.path.join(str(tmp_path), "closed_envmap.json")
+    json.dump(sc, open(path, "w"))
+    return path, px
+
+
+def _expected_envmap(px):
+    h = len(px)
+    c = px.astype(np.float64) / 255.0
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)     # what the 8-bit file holds, decoded
+    theta = np.linspace(0.0, np.pi / 2, 20001)
+    y = theta / np.pi * h - 0.5
+    y0 = np.floor(y).astype(int); t = y - y0
+    row = lambda i: lin[np.mod(i, h)]                                          # repeat addressing; the picture is symmetric anyway
+    L = (row(y0) * (1 - t) + row(y0 + 1) * t) * 1.5
+    f = L * np.cos(theta) * np.sin(theta)
+    E = 2 * np.pi * (f[:-1] + f[1:]).sum() * 0.5 * (theta[1] - theta[0])
+    return np.array([0.6, 0.4, 0.2]) / np.pi * E
+
+
+def _check_envmap(img, px):
+    rgb = img[..., :3].astype(np.float64)
+    floor = rgb[12:, :, :].reshape(-1, 3)
+    exp = _expected_envmap(px)
+    assert np.abs(floor.mean(0) / exp - 1.0).max() < 0.01, (floor.mean(0), exp)
+    # and the map is far from uniform: a uniform environment of the same mean radiance would give a clearly different floor
+    uniform = np.array([0.6, 0.4, 0.2]) * 1.5 * np.mean(_env_rows(len(px)))
+    assert abs(uniform[0] / exp[0] - 1.0) > 0.05
+
+
+def test_banded_environment_map_irradiance_oracle(built, tmp_path):
+    path, px = _scene_envmap(tmp_path)
+    hs, img, cnt = _render_oracle(path, False, spp=512)
+    assert hs.scene.env_light == 0 and hs.scene.lights[0].res_y == 32
+    _check_envmap(img, px)
+
+
+@pytest.mark.gpu
+def test_banded_environment_map_irradiance_gpu(built, tmp_path):
+    path, px = _scene_envmap(tmp_path)
+    hs, img, cnt = _render_gpu(path, False, spp=512)
+    _check_envmap(img, px)
