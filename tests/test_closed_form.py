@@ -620,3 +620,75 @@ def test_banded_environment_map_irradiance_gpu(built, tmp_path):
     path, px = _scene_envmap(tmp_path)
     hs, img, cnt = _render_gpu(path, False, spp=512)
     _check_envmap(img, px)
+
+
+# ---- 12. LightSampler::tidy_up: which light a given u_light picks (lightsampler.cpp:64-74, uniform.cpp:23-34) ----
+# Three delta lights on the camera's axis over the diffuse plane of case 4, listed in the scene file as  point RED, spot GREEN, point BLUE.
+# tidy_up sorts the lights by the index of their topology (class + colour-slot topology) in order of first appearance, so the sampler's
+# table reads  [point RED, point BLUE, spot GREEN]  — the two point lights first, in file order, then the spot.  With max_depth 1 and one
+# sample per pixel the pixel shows exactly ONE light, the one   index = min(u_light * 3, 2)   selects, where u_light is the first draw of
+# the pixel's path stream  tea(tea(px, py), tea(frame, 1))  (independent.cpp:24-27) — known here from the closed form of TEA / LCG, not
+# from the oracle — at   3 * I * albedo / pi * h / (r^2 + h^2)^(3/2)   (pmf 1/3).  A host that keeps the file order (or sorts by type id)
+# shows green where this must be blue.
+TL_H = {"red": 0.5, "green": 0.9, "blue": 0.7}
+TL_I = 2.0
+
+
+def _scene_three_lights(tmp_path):
+    path = _scene_point(tmp_path)
+    sc = json.load(open(path))
+    pos = lambda h: [0.0, -1.0 + h, 0.0]
+    sc["materials"][0]["param"]["color"] = [0.6, 0.4, 0.2]
+    sc["light_sampler"]["param"]["lights"] = [
+        {"type": "point", "name": "red", "param": {"color": [1.0, 0.0, 0.0], "scale": TL_I, "position": pos(TL_H["red"])}},
+        {"type": "spot", "name": "green", "param": {"color": [0.0, 1.0, 0.0], "scale": TL_I, "position": pos(TL_H["green"]), "direction": [0, -1, 0], "angle": 80.0, "falloff": 1.0}},
+        {"type": "point", "name": "blue", "param": {"color": [0.0, 0.0, 1.0], "scale": TL_I, "position": pos(TL_H["blue"])}}]
+    out = os.path.join(str(tmp_path), "closed_three_lights.json")
+    json.dump(sc, open(out, "w"))
+    return out
+
+
+def _first_path_draw(px, py, frame):
+    from test_oracle_golden import tea_np
+    st = int(tea_np(tea_np(px, py), tea_np(frame, 1)))
+    st = (1664525 * st + 1013904223) & 0xFFFFFFFF
+    return np.float32(st & 0xFFFFFF) * np.float32(1.0 / 16777216.0)
+
+
+def _check_three_lights(img):
+    rgb = img[..., :3].astype(np.float64)
+    yy, xx = np.mgrid[0:PL_HGT, 0:PL_W]
+    k = 2.0 * np.tan(np.radians(PL_FOV) / 2.0) / PL_HGT
+    r2 = ((xx + 0.5 - PL_W / 2.0) * k) ** 2 + ((yy + 0.5 - PL_HGT / 2.0) * k) ** 2
+    order = [("red", 0), ("blue", 2), ("green", 1)]  # the table after tidy_up: (light, the one channel it feeds)
+    picked = np.zeros((PL_HGT, PL_W), int)
+    for y in range(PL_HGT):
+        for x in range(PL_W):
+            u = _first_path_draw(x, y, 0)
+            picked[y, x] = int(min(np.float32(u * np.float32(3.0)), np.float32(2.0)))
+    assert all((picked == i).sum() > 150 for i in range(3))  # all three lights are drawn often enough to tell them apart
+    albedo = np.array([0.6, 0.4, 0.2])
+    for i, (name, ch) in enumerate(order):
+        m = picked == i
+        h = TL_H[name]
+        exp = 3.0 * TL_I * albedo[ch] / np.pi * h / (r2[m] + h * h) ** 1.5
+        got = rgb[m]
+        others = [c for c in range(3) if c != ch]
+        assert (got[:, others] == 0.0).all(), (name, "a pixel whose u_light selects this light shows another one")
+        assert np.abs(got[:, ch] / exp - 1.0).max() < 2e-3, (name, np.abs(got[:, ch] / exp - 1.0).max())
+
+
+def test_tidy_up_light_order_closed_form_oracle(built, tmp_path):
+    hs, img, cnt = _render_oracle(_scene_three_lights(tmp_path), False, spp=1)
+    assert hs.scene.n_lights == 3 and hs.params.max_depth == 1
+    assert [hs.scene.lights[i].type for i in range(3)] == [2, 2, 3]  # VMK_LIGHT_POINT, VMK_LIGHT_POINT, VMK_LIGHT_SPOT (include/vmk.h)
+    _check_three_lights(img)
+
+
+@pytest.mark.gpu
+def test_tidy_up_light_order_closed_form_gpu(built, tmp_path):
+    path = _scene_three_lights(tmp_path)
+    hs, img, cnt = _render_gpu(path, False, spp=1)
+    _check_three_lights(img)
+    _, ref, co = _render_oracle(path, False, spp=1)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))

@@ -462,44 +462,98 @@ def test_render_edge_cases(backend, w, h, max_depth, min_depth, tiles):
         assert cg["paths"] == 0 and (img == 0).all()
 
 
-def test_glass_of_water_agrees_with_the_reference_render(backend):
-    """Image-level pin against the reference's OWN output: Vision ships its 1024-spp render of glass-of-water
-    (tests/golden/glass_of_water_ref_blocks.npy = 16x16 block means of that PNG, tools/make_golden_refimage.py).  The poured-water
-    mesh (models/Mesh000.obj: the stream, the water in the glass, the splashes) is missing from the checkout, so the blocks it
-    covers are excluded — and ONLY those.  Everything else is compared and reported by region, under the plain exposure + sRGB
-    encoding that picture carries: (a) backdrop + far table, (b) the rough-conductor table around the objects (metal, GGX),
-    (c) the three ice cubes (rough dielectric: refraction, internal reflection, max depth 32), (d) the strip under the glass, which
-    mirrors the missing water and is only held loosely."""
-    hs, p, osc, _ = _load(backend, "scenes/glass-of-water/vision_scene.json", 1280, 720)
+def _render_linear(backend, spp):
     backend.reset_accum()
-    backend.render_batch(0, 256)
-    lin = backend.download_accum()[..., :3].astype(np.float64)
-    ref = np.load(os.path.join(ROOT, "tests", "golden", "glass_of_water_ref_blocks.npy")).astype(np.float64)
-    B = 16
-    blocks = lambda img: img[:720 // B * B, :1280 // B * B].reshape(720 // B, B, 1280 // B, B, 3).mean((1, 3))
-    srgb = lambda x: np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(np.maximum(x, 1e-12), 1 / 2.4) - 0.055)
-    inv_srgb = lambda y: np.where(y <= 0.04045, y / 12.92, np.power((y + 0.055) / 1.055, 2.4))
-    missing = np.zeros(ref.shape[:2], bool)
-    missing[0:39, 24:54] = True            # the stream, the glass with the water in it, the splashes around its rim
-    region = {"backdrop": np.zeros_like(missing), "table_metal": np.zeros_like(missing), "ice_cubes": np.zeros_like(missing), "under_glass": np.zeros_like(missing)}
-    region["ice_cubes"][33:42, 15:27] = True; region["ice_cubes"][29:38, 54:65] = True
-    region["under_glass"][39:45, 24:54] = True
-    region["table_metal"][31:45, :] = True
-    region["backdrop"][0:31, :] = True
-    for k in ("table_metal", "backdrop"):
-        region[k] &= ~(missing | region["ice_cubes"] | region["under_glass"])
-    mine = blocks(srgb(1.0 - np.exp(-lin)))
-    lin_b, ref_lin = blocks(lin), inv_srgb(ref)
-    limits = {"backdrop": (0.02, 0.15), "table_metal": (0.03, 0.2), "ice_cubes": (0.06, 0.3), "under_glass": (0.12, 0.6)}  # (mean |d| sRGB, energy ratio band)
+    done = 0
+    while done < spp:
+        n = min(128, spp - done)
+        backend.render_batch(done, n); done += n
+    return backend.download_accum()[..., :3].astype(np.float64)
+
+
+def test_cbox_prism_agrees_with_the_reference_render(backend):
+    """Image-level pin against pixels the REFERENCE produced, on a scene with no stripped asset: res/render_scene/cbox/dispersion-hero.png
+    is cbox-prism.json exactly as shipped (LASF9 glass sphere, roughness 0.08, checker back wall, spectrum/hero with 4 wavelengths,
+    1024x1024) — decoded to linear radiance by tools/make_golden_refimage.py (one ACES tone map + sRGB, found by fit; 0.9 % of the
+    pixels, the clipped image of the lamp in the sphere, are excluded on both sides).  ONE global scale is fitted on the diffuse
+    walls; then every region must carry the reference's energy: the interior of the sphere (two refractions through a dispersive
+    dielectric, internal reflections, Russian roulette under eta_scale), its rim (grazing Fresnel reflection), the caustic under it
+    (BSDF-sampled paths through the glass to the lamp) and the textured back wall.  This is independent of this repo's oracle: host
+    encoding, the sphere tessellation, the regenerated rgb -> spectrum table and the whole dielectric chain are on trial.
+    The hero render must also show the reference's COLOUR FRINGES (red-blue chroma at the checker edges seen through the glass)
+    with the same sign and size; the srgb render of the same file must not."""
+    import refimage_util as ru
+    z, valid, refb = ru.load("cbox_prism_ref.npz")
+    shape = (1024, 1024)
+    disc = lambda x, y, r: ((x - 600) ** 2 + (y - 490) ** 2) < r * r
+    R = {"red_wall": ru.block_mask(shape, lambda x, y: (x >= 10) & (x < 100) & (y >= 300) & (y < 800)),
+         "green_wall": ru.block_mask(shape, lambda x, y: (x >= 930) & (x < 1010) & (y >= 200) & (y < 560)),
+         "ceiling": ru.block_mask(shape, lambda x, y: (y >= 20) & (y < 100) & (((x >= 250) & (x < 420)) | ((x >= 600) & (x < 780)))),
+         "floor": ru.block_mask(shape, lambda x, y: (x >= 100) & (x < 300) & (y >= 920) & (y < 1000)),
+         "back_wall": ru.block_mask(shape, lambda x, y: (x >= 140) & (x < 380) & (y >= 160) & (y < 860)),
+         "sphere": ru.block_mask(shape, lambda x, y: disc(x, y, 170)),
+         "sphere_rim": ru.block_mask(shape, lambda x, y: disc(x, y, 204) & ~disc(x, y, 175)),
+         "caustic": ru.block_mask(shape, lambda x, y: (x >= 520) & (x < 800) & (y >= 920) & (y < 995))}
+    walls = R["red_wall"] | R["green_wall"] | R["ceiling"] | R["floor"]
+    yy, xx = np.mgrid[330:650, 440:760]
+    inner = disc(xx, yy, 160) & valid[330:650, 440:760]
+    ref_fr = z["fringe"].astype(np.float64)[inner]
+    strong = np.abs(ref_fr) > 3 * ref_fr.std()
     report = {}
-    for k, m in region.items():
-        d = np.abs(mine - ref)[m].mean()
-        ratio = lin_b[m].sum(0) / ref_lin[m].sum(0)
-        report[k] = (int(m.sum()), float(d), [float(x) for x in ratio])
-    print("glass-of-water vs the reference's render, by region (blocks, mean |d| in sRGB units, linear energy ratio RGB):", report)
-    for k, (n, d, ratio) in report.items():
-        assert n > 50 and d < limits[k][0], (k, d)
-        assert all(abs(r - 1.0) < limits[k][1] for r in ratio), (k, ratio)
+    for spectrum in (None, "srgb"):  # as shipped (hero, 4 wavelengths), then the same file under spectrum/srgb
+        hs, p, osc, _ = _load(backend, "scenes/cbox/cbox-prism.json", 1024, 1024, **({"spectrum": spectrum} if spectrum else {}))
+        lin = _render_linear(backend, 1024)
+        mb = ru.block_sums(lin, valid)
+        k = refb[walls].sum() / mb[walls].sum()
+        ratios = ru.region_ratios(mb * k, refb, R)
+        fr = ru.fringe_map(lin * k)[330:650, 440:760][inner]
+        agree = float((np.sign(fr[strong]) == np.sign(ref_fr[strong])).mean())
+        proj = float((fr[strong] * np.sign(ref_fr[strong])).mean())
+        report[spectrum or "hero4"] = (k, {a: [round(float(v), 3) for v in b] for a, b in ratios.items()}, agree, proj)
+        print("cbox-prism vs the reference's render:", spectrum or "hero4 (as shipped)", "scale %.4f" % k, report[spectrum or "hero4"][1],
+              "fringes: sign agreement %.3f, mean projection %.3f (reference %.3f, %d pixels)" % (agree, proj, float(np.abs(ref_fr[strong]).mean()), int(strong.sum())))
+        assert abs(k - 1.0) < 0.06, k  # the picture carries exposure 1: no hidden scale
+        luma = lambda r: float(np.dot(r, [0.2126, 0.7152, 0.0722]))
+        for name in ("back_wall", "sphere", "sphere_rim", "caustic", "floor", "ceiling"):
+            assert abs(luma(ratios[name]) - 1.0) < 0.05, (name, ratios[name])          # energy within the walls' ratio +- 5 %
+        for name in ("back_wall", "sphere", "floor") + (("sphere_rim", "caustic") if spectrum is None else ()):
+            assert np.abs(ratios[name] - 1.0).max() < 0.05, (name, ratios[name])       # ... and per channel where the light is white
+        for name in ("red_wall", "green_wall"):
+            assert np.abs(ratios[name] - 1.0).max() < 0.08, (name, ratios[name])       # (the dark channels of the coloured walls sit at 8-bit levels ~40)
+    ref_size = float(np.abs(ref_fr[strong]).mean())
+    assert strong.sum() > 500 and ref_size > 0.3
+    assert report["hero4"][2] > 0.97 and abs(report["hero4"][3] / ref_size - 1.0) < 0.1, report["hero4"]   # the fringes are there, same sign, same size
+    assert report["srgb"][3] < 0.15 * ref_size, report["srgb"]                                            # and they are dispersion, not geometry
+
+
+def test_glass_of_water_agrees_with_the_reference_render(backend):
+    """Second picture of the reference's own: its 1024-spp render of glass-of-water (tests/golden/glass_of_water_ref.npz: decoded
+    with the exposure curve 1 - exp(-x) + sRGB that picture carries, clipped sparkles excluded, tools/make_golden_refimage.py).  The
+    poured-water mesh (models/Mesh000.obj: the stream, the water in the glass, the splashes) is missing from the checkout, so the blocks
+    it covers are excluded — and ONLY those.  Regions: (a) backdrop + far table, (b) the rough-conductor table (measured metal, GGX),
+    (c) the three ice cubes (ROUGH dielectric: refraction, internal reflection, max depth 32), (d) the strip under the glass, which
+    mirrors the missing water and is only held loosely.  The picture's colour balance is known only by fit (R -11 %), so the regions
+    are judged against the backdrop's ratio.
+    (Round 2 compared linear sums with sums of 1 - exp(-x) and read a 14-27 % "excess" on the ice cubes: that was the exposure
+    curve, which compresses bright regions; decoded properly the cubes sit at 1.00 / 0.94 / 0.92 of the backdrop's ratio.)"""
+    import refimage_util as ru
+    hs, p, osc, _ = _load(backend, "scenes/glass-of-water/vision_scene.json", 1280, 720)
+    lin = _render_linear(backend, 512)
+    z, valid, refb = ru.load("glass_of_water_ref.npz")
+    shape = (720, 1280)
+    blk = lambda r0, r1, c0, c1: ru.block_mask(shape, lambda x, y: (y >= r0 * 16) & (y < r1 * 16) & (x >= c0 * 16) & (x < c1 * 16))
+    missing = blk(0, 39, 24, 54)  # the stream, the glass with the water in it, the splashes around its rim
+    R = {"ice_cubes": blk(33, 42, 15, 27) | blk(29, 38, 54, 65), "under_glass": blk(39, 45, 24, 54)}
+    R["table_metal"] = blk(31, 45, 0, 80) & ~(missing | R["ice_cubes"] | R["under_glass"])
+    R["backdrop"] = blk(0, 31, 0, 80) & ~missing
+    ratios = ru.region_ratios(ru.block_sums(lin, valid), refb, R)
+    rel = {k: v / ratios["backdrop"] for k, v in ratios.items()}
+    print("glass-of-water vs the reference's render, linear energy ratio RGB by region:", {k: [round(float(x), 3) for x in v] for k, v in ratios.items()},
+          "relative to the backdrop:", {k: [round(float(x), 3) for x in v] for k, v in rel.items()})
+    assert np.abs(ratios["backdrop"] - 1.0).max() < 0.13, ratios["backdrop"]
+    limits = {"table_metal": 0.06, "ice_cubes": 0.10, "under_glass": 0.12}
+    for k, lim in limits.items():
+        assert np.abs(rel[k] - 1.0).max() < lim, (k, rel[k])
 
 
 def test_classroom_sky_through_the_fog_is_attenuated_over_the_world_diameter(backend):

@@ -1,22 +1,76 @@
 #!/usr/bin/env python3
-"""Goldens from reference OUTPUT files (data only): block means of pictures the reference itself rendered and ships.
+"""Goldens from reference OUTPUT files (data only): pictures the reference itself rendered and ships, decoded to LINEAR radiance.
 
-  res/render_scene/glass-of-water/glass-of-water-1024spp.png  -> tests/golden/glass_of_water_ref_blocks.npy  (16x16 blocks)
+  res/render_scene/cbox/dispersion-hero.png                    -> tests/golden/cbox_prism_ref.npz
+      = res/render_scene/cbox/cbox-prism.json exactly as shipped (glass sphere LASF9, checker back wall, spectrum/hero dimension 4,
+      1024x1024; scenes/cbox/cbox-prism.json is that file).  Encoding found by fit on the diffuse walls: ONE ACES tone map
+      (exposure 1) + sRGB; gallery/dispersion.png is the same picture through the double tone map of Pipeline::final_picture.
+  res/render_scene/glass-of-water/glass-of-water-1024spp.png   -> tests/golden/glass_of_water_ref.npz
+      Encoding: exposure 1 - exp(-x) + sRGB (not saved through final_picture).
 
-sRGB-encoded values in [0, 1] as float16.  The GPU tests render the same scenes with this framework and compare the parts that
-do not depend on assets missing from the checkout.   python tools/make_golden_refimage.py
+Stored per picture: `valid` = packed bits of the pixels whose 8-bit value is NOT saturated (any channel > 0.97, dilated by 8 / 4
+pixels: an inverse tone map cannot recover clipped highlights — the image of the lamp in the sphere, the sparkles on the ice), and
+`lin` = 8x8 block sums of the decoded linear radiance over the valid pixels (float32).  For the dispersion picture also `fringe`:
+the high-passed red-blue chroma (R - B) / (R + G + B) inside the sphere, float16 — the colour fringes the hero spectrum produces at
+the checker edges seen through the dispersive glass.
+
+Pictures examined and NOT usable as pins (different scene state than any shipped file): res/render_scene/cbox/dispersion-srgb.png,
+srgb.png, hero.png, hero2.png, dispersion-hero2.png (dark back wall / prism / box variants of the Cornell scene), and
+gallery/staircase.png (the shipped staircase/vision_scene.json has the Tungsten camera, which shows the arch in the foreground; the
+gallery picture was taken from another position and pitch after moving the camera in the GUI: no crop or zoom of the shipped view
+reproduces it).   python tools/make_golden_refimage.py
 """
 import os
 import numpy as np
 from PIL import Image
+from scipy.ndimage import binary_dilation, gaussian_filter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/res/render_scene"
-# (the two classroom PNGs are not usable as pins: see DESIGN.md section 2)
-for src, name, B in ((f"{REF}/glass-of-water/glass-of-water-1024spp.png", "glass_of_water_ref_blocks.npy", 16),):
-    img = np.asarray(Image.open(src).convert("RGB")).astype(np.float64) / 255.0
+B = 8
+
+
+def inv_srgb(y):
+    return np.where(y <= 0.04045, y / 12.92, np.power((y + 0.055) / 1.055, 2.4))
+
+
+def inv_aces(y):  # y = x (a x + b) / (x (c x + d) + e), tonemapper/impl.cpp:27-34
+    a, b, c, d, e = 2.51, 0.03, 2.43, 0.59, 0.14
+    y = np.clip(y, 0.0, 0.999)
+    A, Bq, C = a - c * y, b - d * y, -e * y
+    return (-Bq + np.sqrt(np.maximum(Bq * Bq - 4 * A * C, 0.0))) / (2 * A)
+
+
+def inv_exposure(y):  # 1 - exp(-x * exposure), exposure 1 (frame_buffer.cpp:135-144)
+    return -np.log(np.maximum(1.0 - y, 1e-5))
+
+
+def block_sums(img, valid):
     h, w, _ = img.shape
-    blocks = img[:h // B * B, :w // B * B].reshape(h // B, B, w // B, B, 3).mean((1, 3))
-    out = os.path.join(ROOT, "tests", "golden", name)
-    np.save(out, blocks.astype(np.float16))
-    print(out, blocks.shape, blocks.mean())
+    v = img * valid[..., None]
+    return v[:h // B * B, :w // B * B].reshape(h // B, B, w // B, B, 3).sum((1, 3)).astype(np.float32)
+
+
+def fringe_map(lin):
+    """(R - B) / (R + G + B), lightly smoothed, minus its own low-pass: what is left are the colour fringes at edges."""
+    img = gaussian_filter(lin, (1.5, 1.5, 0))
+    c = (img[..., 0] - img[..., 2]) / (img.sum(2) + 1e-3)
+    return c - gaussian_filter(c, 12)
+
+
+if __name__ == "__main__":
+    # ---- cbox-prism ----
+    ref = np.asarray(Image.open(f"{REF}/cbox/dispersion-hero.png").convert("RGB")).astype(np.float64) / 255.0
+    valid = ~binary_dilation(ref.max(2) > 0.97, iterations=8)
+    lin = inv_aces(inv_srgb(ref))
+    fr = fringe_map(lin)[330:650, 440:760]  # the sphere's bounding box (centre (600, 490), radius 208 px)
+    out = os.path.join(ROOT, "tests", "golden", "cbox_prism_ref.npz")
+    np.savez_compressed(out, valid=np.packbits(valid), lin=block_sums(lin, valid), fringe=fr.astype(np.float16), shape=np.array(ref.shape[:2]))
+    print(out, "valid", valid.mean(), "mean", lin[valid].mean(0))
+    # ---- glass-of-water ----
+    ref = np.asarray(Image.open(f"{REF}/glass-of-water/glass-of-water-1024spp.png").convert("RGB")).astype(np.float64) / 255.0
+    valid = ~binary_dilation(ref.max(2) > 0.97, iterations=4)
+    lin = inv_exposure(inv_srgb(ref))
+    out = os.path.join(ROOT, "tests", "golden", "glass_of_water_ref.npz")
+    np.savez_compressed(out, valid=np.packbits(valid), lin=block_sums(lin, valid), shape=np.array(ref.shape[:2]))
+    print(out, "valid", valid.mean(), "mean", lin[valid].mean(0))

@@ -415,6 +415,11 @@ struct HostScene {
         return parse_slot_json(param[key], key, dim, def, env_image);
     }
     // a slot description: a bare value / array, {"channels", "node"}, or a node object (number / constant / image / multiply)
+    // The TOPOLOGY of the slot parsed last, as a string: what ShaderNodeSlot::compute_topology_hash (shader_node.cpp:187-189) hashes —
+    // channel mask, dimension, the node's own topology: a number node's is (value count, min, max) (number.cpp:18), an image node's
+    // the reduction over its inner slots, which no scene file can change (image.cpp:14-36: the file name and the scale are values, not
+    // topology), a binary node's that of its operands (math.cpp:71-73).  LightSampler::tidy_up groups the lights by it.
+    std::string slot_topology;
     vmk_slot parse_slot_json(const Json &ps, const std::string &key, int dim, std::vector<float> def, bool env_image = false) {
         vmk_slot sl{}; sl.tex = VMK_INVALID;
         std::string channels = dim == 1 ? "x" : "xyz";
@@ -422,7 +427,9 @@ struct HostScene {
         if (ps.is_object() && ps.contains("channels")) { channels = ps["channels"].as_string(channels); node = &ps["node"]; }
         std::vector<float> value = def;
         std::string fn, color_space; float tex_scale = 1.f; bool is_image = false;
-        if (node->is_null()) { /* default */ }
+        float num_min = 0.f, num_max = 1.f; // NumberArray's range (number.cpp:24-25; ShaderNodeDesc::init node_desc.cpp:322-327)
+        std::string node_kind = "number";
+        if (node->is_null()) { node_kind = "none"; }
         else if (node->is_array()) value = node->as_float_vector();
         else if (node->is_number()) value = {node->as_float(0.f)};
         else if (node->is_object()) {
@@ -431,17 +438,31 @@ struct HostScene {
             if (!node->contains("param")) type = (*node)["type"].as_string("image");
             else { type = (*node)["type"].as_string(); p = &(*node)["param"]; }
             if (type == "image") { is_image = true; fn = (*p)["fn"].as_string(); color_space = (*p)["color_space"].as_string(); tex_scale = (*p)["scale"].as_float(1.f); }
-            else if (type == "number" || type == "constant") { const Json &v = (*p)["value"]; if (!v.is_null()) value = v.as_float_vector(); }
-            else if (type == "multiply") return parse_multiply(*p, key, channels, dim, env_image);
+            else if (type == "number" || type == "constant") {
+                const Json &v = (*p)["value"]; if (!v.is_null()) value = v.as_float_vector();
+                if (type == "number") { num_min = (*p)["min"].as_float(0.f); num_max = (*p)["max"].as_float(1.f); }
+                node_kind = type;
+            }
+            else if (type == "multiply") {
+                vmk_slot r = parse_multiply(*p, key, channels, dim, env_image);
+                slot_topology = "slot(" + std::to_string(channel_mask(channels, dim)) + "," + std::to_string(dim) + "," + slot_topology + ")";
+                return r;
+            }
             else fail("shader node type '" + type + "' (slot '" + key + "') is outside the hot-path scope (number / constant / image / multiply of an image and a constant)");
         }
         if (is_image) {
             uint32_t id = obtain_texture(fn, color_space, env_image);
             sl.v[0] = tex_scale; sl.v[1] = sl.v[2] = 0.f;
             sl.tex = (id & 0xffffu) | (channel_mask(channels, dim) << 16);
+            slot_topology = "slot(" + std::to_string(channel_mask(channels, dim)) + "," + std::to_string(dim) + ",image)";
             return sl;
         }
         if (value.empty()) value = def;
+        {   // (a scalar given for a 3-channel slot is replicated BEFORE the node is built, node_desc.cpp:137-143, so its value count is dim)
+            size_t count = (dim > 1 && value.size() == 1 && !node->is_array()) ? (size_t) dim : value.size();
+            char buf[96]; snprintf(buf, sizeof buf, "%s(%zu,%g,%g)", node_kind.c_str(), count, (double) num_min, (double) num_max);
+            slot_topology = "slot(" + std::to_string(channel_mask(channels, dim)) + "," + std::to_string(dim) + "," + buf + ")";
+        }
         if ((int) channels.size() > 1 && value.size() == 1) value = std::vector<float>(channels.size(), value[0]); // scalar broadcast
         float c[4] = {0, 0, 0, 0};
         for (size_t i = 0; i < value.size() && i < 4; ++i) c[i] = value[i];
@@ -455,7 +476,9 @@ struct HostScene {
     // for the latter (the slot has no room for both, and (t * s) * c is not t * (s * c) in float32).
     vmk_slot parse_multiply(const Json &p, const std::string &key, const std::string &channels, int dim, bool env_image) {
         vmk_slot l = parse_slot_json(p["lhs"], key + ".lhs", 3, {1.f, 1.f, 1.f}, env_image);
+        const std::string topo_l = slot_topology;
         vmk_slot r = parse_slot_json(p["rhs"], key + ".rhs", 3, {1.f, 1.f, 1.f}, env_image);
+        slot_topology = "multiply(" + topo_l + "," + slot_topology + ")";
         const bool li = l.tex != VMK_INVALID, ri = r.tex != VMK_INVALID;
         if (li && ri) fail("slot '" + key + "': a multiply node of two images is outside the hot-path scope (image x constant, constant x constant)");
         if ((li && (l.tex & VMK_SLOT_TINTED)) || (ri && (r.tex & VMK_SLOT_TINTED))) fail("slot '" + key + "': nested multiply nodes over an image are outside the hot-path scope");
@@ -749,9 +772,11 @@ struct HostScene {
     }
 
     // Light::Light + initialize_slots (light.cpp:10-24): colour normalised so max component <= 1, factor folded into scale
+    std::string light_topology; // of the light initialised last: Light::compute_topology_hash = color_.topology_hash() (light.h:114-116)
     void init_light_color(vmk_light &l, const Json &p, bool env) {
         l.scale = p["scale"].as_float(1.f);
         l.color = parse_slot(p, "color", 3, {0.5f, 0.5f, 0.5f}, env);
+        light_topology = slot_topology;
         if (l.color.tex == VMK_INVALID) { // NumberArray::normalize (number.cpp:38-47)
             float mx = std::max(l.color.v[0], std::max(l.color.v[1], l.color.v[2]));
             if (!(mx < 1.f)) { for (float &c : l.color.v) c = c / mx; l.scale = l.scale * mx; }
@@ -823,7 +848,7 @@ struct HostScene {
         params.light_sampler = ls_type == "power" ? 1u : 0u;
         params.env_separate = lsd["param"]["env_separate"].as_bool(false) ? 1u : 0u;
         params.env_prob = std::min(0.99f, std::max(0.01f, lsd["param"]["env_prob"].as_float(0.5f)));
-        struct PendingLight { vmk_light l; int order; };
+        struct PendingLight { vmk_light l; int order; std::string topo; };
         std::vector<PendingLight> pending;
         for (auto &ld : lsd["param"]["lights"].arr) {
             std::string type = ld["type"].as_string("area");
@@ -837,7 +862,7 @@ struct HostScene {
                 Mat4 w2o_f{}; for (int i = 0; i < 16; ++i) w2o_f.m[i] = (double) (float) w2o.m[i];
                 Mat4 o2w_back = inverse(w2o_f); // spherical.cpp:114 evaluates inverse(*w2o_) per sample
                 for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) { l.w2o[c * 3 + r] = (float) w2o.at(r, c); l.o2w[c * 3 + r] = (float) o2w_back.at(r, c); }
-                pending.push_back({l, 1});
+                pending.push_back({l, 1, "spherical|" + light_topology});
                 describe("light", "spherical", ld["name"].as_string());
             } else if (type == "point" || type == "spot") { // point.cpp:19-30, spot.cpp:19-38
                 vmk_light l{}; l.type = type == "point" ? VMK_LIGHT_POINT : VMK_LIGHT_SPOT; l.inst_id = VMK_INVALID;
@@ -860,7 +885,7 @@ struct HostScene {
                     l.cos_angle = std::cos(angle);
                     l.cos_falloff_start = std::cos(std::max(0.f, angle - falloff));
                 }
-                pending.push_back({l, 0});
+                pending.push_back({l, 0, type + "|" + light_topology});
                 describe("light", type, ld["name"].as_string());
             } else if (type == "projector") { // projector.cpp:31-49
                 vmk_light l{}; l.type = VMK_LIGHT_PROJECTOR; l.inst_id = VMK_INVALID;
@@ -882,7 +907,7 @@ struct HostScene {
                 for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) l.w2o4[c * 4 + r] = (float) w2o.at(r, c);
                 for (int k = 0; k < 3; ++k) l.position[k] = (float) o2w_f.at(k, 3);                           // position() = o2w_[3].xyz (:91)
                 for (int k = 0; k < 3; ++k) l.direction[k] = (float) o2w_f.at(k, 2);                          // direction() = transform_vector(o2w_, (0, 0, 1)) (:95-97)
-                pending.push_back({l, 0});
+                pending.push_back({l, 0, type + "|" + light_topology});
                 describe("light", type, ld["name"].as_string());
             } else if (type == "area") {
                 fail("stand-alone light/area (own quad geometry, area.cpp:56-71) is outside the hot-path scope; use shape.param.emission");
@@ -926,21 +951,28 @@ struct HostScene {
                 vmk_light l{}; l.type = VMK_LIGHT_AREA; l.inst_id = inst_id;
                 init_light_color(l, em["param"], false);
                 l.two_sided = em["param"]["two_sided"].as_bool(false) ? 1u : 0u;
-                pending.push_back({l, 0});
+                pending.push_back({l, 0, "area|" + light_topology});
                 describe("light", "area", sd["name"].as_string());
             }
         }
 
-        // ---- LightSampler::tidy_up: lights grouped by topology (type) in first-seen order (lightsampler.cpp:64-74) ----
+        // ---- LightSampler::tidy_up (lightsampler.cpp:64-74): std::sort of the lights by `lights_.topology_index(light)` ----
+        // The index comes from ocarina's Polymorphic container (absent from the checkout; restated from its use): a light's topology is
+        // its class together with Light::compute_topology_hash() = color_.topology_hash() (light.h:114-116; the slot's hash covers the
+        // channel mask, the dimension and the node's topology, shader_node.cpp:187-189 — see slot_topology above), and a topology's
+        // index is its rank of FIRST APPEARANCE among the lights in the order Scene::init registers them: the light sampler's own
+        // list (scene.cpp:16-35 loads the sampler first), then one area light per emissive shape in shape order (scene.cpp:120-163).
+        // Lights of one topology keep their registration order: the comparator never orders them, and every std::sort in use
+        // (MSVC <= 32 elements, libstdc++ <= 16) finishes such a range with a stable insertion sort; the shipped scenes have <= 13
+        // lights.  Beyond 16 lights the reference's order is whatever its standard library's introsort leaves — implementation
+        // defined there, the registration order here, and said so in the scene description.
         {
-            std::vector<uint32_t> first_seen; // type order of first appearance
-            auto topo = [](const vmk_light &l) { return l.type * 2u + (l.color.tex != VMK_INVALID ? 1u : 0u); };
-            for (auto &pl : pending) { uint32_t t = topo(pl.l); if (std::find(first_seen.begin(), first_seen.end(), t) == first_seen.end()) first_seen.push_back(t); }
-            std::stable_sort(pending.begin(), pending.end(), [&](const PendingLight &a, const PendingLight &b) {
-                auto ia = std::find(first_seen.begin(), first_seen.end(), topo(a.l)) - first_seen.begin();
-                auto ib = std::find(first_seen.begin(), first_seen.end(), topo(b.l)) - first_seen.begin();
-                return ia < ib;
-            });
+            std::vector<std::string> first_seen; // topology -> index of first appearance
+            auto index_of = [&](const std::string &t) { return (size_t) (std::find(first_seen.begin(), first_seen.end(), t) - first_seen.begin()); };
+            for (auto &pl : pending) if (index_of(pl.topo) == first_seen.size()) first_seen.push_back(pl.topo);
+            std::stable_sort(pending.begin(), pending.end(), [&](const PendingLight &a, const PendingLight &b) { return index_of(a.topo) < index_of(b.topo); });
+            if (pending.size() > 16 && first_seen.size() > 1)
+                describe("lightsampler", "tidy_up", std::to_string(pending.size()) + " lights of " + std::to_string(first_seen.size()) + " topologies: beyond 16 the reference's order is std::sort-implementation-defined; registration order kept");
         }
         double ext[3] = {bmax[0] - bmin[0], bmax[1] - bmin[1], bmax[2] - bmin[2]};
         double aabb_radius = tri_pos.empty() ? 0.0 : 0.5 * std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
