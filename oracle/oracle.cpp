@@ -305,28 +305,67 @@ inline Spec eval_slot_spd(const vmk_scene *s, const vmk_slot &sl, float2 uv) { /
 
 // =====================================================================================================
 // a4. ray / triangle / BVH — Geometry::trace_closest / trace_occlusion (geometry.cpp:168-185)
-// The reference delegates to OptiX; the restatement is a Moeller-Trumbore test with the hit-selection rule
-// "smallest t wins, ties resolved towards the smaller (inst, prim)", valid hits 0 < t < t_max.
+// The reference delegates to OptiX, whose triangle test is WATERTIGHT: a ray aimed at an edge or a vertex shared by two triangles hits
+// (at least) one of them.  The restatement is the published watertight test of Woop, Benthin and Wald (JCGT 2013, "Watertight
+// Ray/Triangle Intersection") in float32 — vertices translated to the ray origin, permuted so that the ray's dominant axis is z, sheared
+// so that the ray runs along +z, then three 2-D edge functions.  An edge function is computed from the two sheared vertices of ITS edge
+// only, with commutative products and one subtraction, so the two triangles that share an edge see values that are equal or exactly
+// negated: the ray cannot be outside both.  Zeros count as inside for either sign (no double-precision fallback: an edge-on ray may
+// report both neighbours, and the selection rule below picks one).  The hit distance is taken from the plane equation (below).  Hit-selection rule: valid hits 0 < t < t_max, smallest t wins,
+// ties resolved towards the smaller (inst, prim).  Barycentrics: u weighs p1, v weighs p2.
 // =====================================================================================================
 struct Ray { float3 o; float3 d; float t_max; };
 struct Hit { uint32_t inst{VMK_INVALID}, prim{VMK_INVALID}; float2 bary{0, 0}; uint32_t tri{VMK_INVALID};
              bool is_miss() const { return inst == VMK_INVALID; } };
 
+// The permutation puts the ray's dominant axis kz (first maximum of |d|) in z; the other two axes go to x and y in whichever order
+// costs one select each (every quantity below is invariant under swapping them): kz = 0 -> (y, z, x), 1 -> (x, z, y), 2 -> (x, y, z).
+inline float3 tri_permute(float3 v, bool k0, bool k2) {
+    float3 r;
+    r.x = k0 ? v.y : v.x;
+    r.y = k2 ? v.y : v.z;
+    r.z = k2 ? v.z : (k0 ? v.x : v.y);
+    return r;
+}
 inline bool intersect_tri(const vmk_tri_pos &tp, float3 o, float3 d, float *t_out, float *u_out, float *v_out) {
     float3 p0 = {tp.p0[0], tp.p0[1], tp.p0[2]}, p1 = {tp.p1[0], tp.p1[1], tp.p1[2]}, p2 = {tp.p2[0], tp.p2[1], tp.p2[2]};
-    float3 e1 = p1 - p0, e2 = p2 - p0;
-    float3 pvec = cross(d, e2);
-    float det = dot(e1, pvec);
+    // per-ray constants (the device keeps them with the ray): dominant axis, shear
+    float ax = abs_(d.x), ay = abs_(d.y), az = abs_(d.z);
+    bool k1 = ay > ax;
+    bool k2 = az > (k1 ? ay : ax);
+    bool k0 = !k1 && !k2;
+    float3 dp = tri_permute(d, k0, k2);
+    float Sz = 1.f / dp.z, Sx = dp.x * Sz, Sy = dp.y * Sz;
+    // vertices relative to the ray origin, permuted
+    float3 A = tri_permute(p0 - o, k0, k2), B = tri_permute(p1 - o, k0, k2), C = tri_permute(p2 - o, k0, k2);
+    // sheared x, y: the ray runs along +z through the origin
+    float Ax = A.x - Sx * A.z, Ay = A.y - Sy * A.z;
+    float Bx = B.x - Sx * B.z, By = B.y - Sy * B.z;
+    float Cx = C.x - Sx * C.z, Cy = C.y - Sy * C.z;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    // outside iff the edge functions disagree in sign (zeros are inside for either sign; minNum / maxNum ignore a NaN operand)
+    float lo = fmin_(fmin_(U, V), W), hi = fmax_(fmax_(U, V), W);
+    if (lo < 0.f && hi > 0.f) return false;
+    float det = U + V + W;
     if (det == 0.f) return false;
+    // The distance comes from the triangle's PLANE in the unsheared frame, not from interpolating the sheared depths (the paper's
+    // T = U Az + V Bz + W Cz carries an absolute error of eps * |vertex - o|: on a large floor or wall quad that exceeds the offset a
+    // spawned ray starts with, and shadow rays would hit the surface they leave):  t = (A . N) / (d' . N),  N = (C - A) x (B - A),
+    // d' . N = d_z (Sx Nx + Sy Ny + Nz) = d_z * det  (the z component of a normal is what a shear along z leaves unchanged), so the one
+    // reciprocal of det serves t, u and v.  For an axis-aligned quad the in-plane components of N are exact zeros and t is exact.
+    float3 e1 = B - A, e2 = C - A;
+    float3 N = cross(e2, e1); // this orientation has N . (Sx, Sy, 1) = U + V + W
     float inv = 1.f / det;
-    float3 tvec = o - p0;
-    float u = dot(tvec, pvec) * inv;
-    if (!(u >= 0.f && u <= 1.f)) return false;
-    float3 qvec = cross(tvec, e1);
-    float v = dot(d, qvec) * inv;
-    if (!(v >= 0.f && u + v <= 1.f)) return false;
-    float t = dot(e2, qvec) * inv;
-    *t_out = t; *u_out = u; *v_out = v;
+    float t = dot(A, N) * Sz * inv;
+    // A hit lies within the triangle's own extent along the ray's dominant axis: t * d_z in [min z, max z] of the three vertices
+    // (padded by 2^-14).  For a well-conditioned test this is implied; for a triangle seen edge-on (U, V, W and det all rounding noise,
+    // t arbitrary) it is what keeps a hit from being reported far outside the triangle's bounding box — such a hit would be found or
+    // not depending on whether its leaf was culled against an earlier hit, i.e. on the traversal order.
+    float zlo = fmin_(fmin_(A.z, B.z), C.z) * Sz, zhi = fmax_(fmax_(A.z, B.z), C.z) * Sz;
+    float tlo = fmin_(zlo, zhi), thi = fmax_(zlo, zhi);
+    const float pad = 1.f / 16384.f;
+    if (!(t * (1.f + pad) >= tlo && t * (1.f - pad) <= thi)) return false;
+    *t_out = t; *u_out = V * inv; *v_out = W * inv;
     return true;
 }
 

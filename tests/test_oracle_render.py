@@ -143,8 +143,8 @@ def test_config0_cbox_256x256_16spp_on_cpu(built):
     hs = HostScene(os.path.join(ROOT, "scenes/cbox/cbox_matte.json"), width=256, height=256)
     img, cnt = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, 16)
     assert cnt["paths"] == 256 * 256 * 16 and (cnt["closest_rays"], cnt["shadow_rays"]) == (3266952, 2837842)
-    assert np.isfinite(img).all() and abs(float(img[..., :3].mean()) - 0.12030963) < 1e-6
-    assert hashlib.sha1(img.tobytes()).hexdigest() == "d1091f91e538ad218d058984b94095a981f874da"
+    assert np.isfinite(img).all() and abs(float(img[..., :3].mean()) - 0.12030959) < 1e-6
+    assert hashlib.sha1(img.tobytes()).hexdigest() == "289c353a54e7b19d6027543dc0abaec98e5f05a3"
 
 
 @pytest.mark.parametrize("scene", ["scenes/cbox/cbox_matte.json", "scenes/cbox/cbox_lights.json"])

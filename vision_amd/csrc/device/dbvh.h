@@ -1,7 +1,7 @@
 // dbvh.h — wave-cooperative BVH4 traversal: 4 lanes per ray, 16 rays in flight per wave64.
 // Replaces ocarina::Accel trace_closest / trace_occlusion (base/mgr/geometry.cpp:168-185; OptiX in the reference).
 // Hit selection rule (shared with the oracle): valid hits 0 < t < t_max, smallest t wins, equal t resolved towards
-// the smaller (inst, prim).  Triangle test: Moeller-Trumbore on world-space vertices, IEEE float32, no contraction.
+// the smaller (inst, prim).  Triangle test: watertight (Woop et al.) on world-space vertices, IEEE float32, no contraction.
 //
 // Why quads.  With one ray per lane (the first design) the counters on classroom read: 12.9 of 64 lanes
 // active per VALU op and the texture-addresser (TA) 73 % busy — a wave64 memory instruction occupies the TA for ~19
@@ -49,25 +49,57 @@ constexpr int kQuadXor1 = 0xB1; // quad_perm:[1,0,3,2]
 constexpr int kQuadXor2 = 0x4E; // quad_perm:[2,3,0,1]
 constexpr int kQuadXor3 = 0x1B; // quad_perm:[3,2,1,0]
 
-VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, V3 d, float *t_out, float *u_out, float *v_out, uint32_t *inst_out, uint32_t *prim_out) {
+// Watertight ray / triangle test (Woop, Benthin, Wald, JCGT 2013) in float32, bit-identical to the oracle's restatement: vertices
+// translated to the ray origin, permuted so that the ray's dominant axis is z, sheared so that the ray runs along +z, three 2-D edge
+// functions.  Each edge function is computed from the two sheared vertices of its edge alone (commutative products, one subtraction),
+// so two triangles that share an edge see equal or exactly negated values and a ray cannot slip between them — what OptiX guarantees
+// behind the reference's trace_closest (geometry.cpp:168-174).  Zeros are inside for either sign.  u weighs p1, v weighs p2.
+// Per-ray constants of the test, computed once when a quad takes a ray: the dominant axis kz of d (first maximum of |d|; k0: kz == 0,
+// k2: kz == 2) and the shear (Sx, Sy, Sz) = (d_x' / d_z', d_y' / d_z', 1 / d_z') in the permuted frame.  The traversal keeps these
+// instead of d.  The two minor axes go to x and y in whichever order costs one select each (kz = 0 -> (y, z, x), 1 -> (x, z, y),
+// 2 -> (x, y, z)): every quantity of the test is invariant under swapping them.
+struct TriRay { V3 S; bool k0, k2; };
+VD V3 tri_permute(V3 v, bool k0, bool k2) { return mk3(k0 ? v.y : v.x, k2 ? v.y : v.z, k2 ? v.z : (k0 ? v.x : v.y)); }
+VD TriRay tri_ray_setup(V3 d) {
+    const float ax = abs_(d.x), ay = abs_(d.y), az = abs_(d.z);
+    const bool k1 = ay > ax;
+    TriRay r;
+    r.k2 = az > (k1 ? ay : ax);
+    r.k0 = !k1 && !r.k2;
+    const V3 dp = tri_permute(d, r.k0, r.k2);
+    r.S.z = 1.f / dp.z; r.S.x = dp.x * r.S.z; r.S.y = dp.y * r.S.z;
+    return r;
+}
+VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, const TriRay &R, float *t_out, float *u_out, float *v_out, uint32_t *inst_out, uint32_t *prim_out) {
     // 48 B record as three 16 B loads
     const float4 *q = reinterpret_cast<const float4 *>(tp);
     float4 a = ldg(q), b = ldg(q + 1), c = ldg(q + 2);
     V3 p0 = {a.x, a.y, a.z}, p1 = {a.w, b.x, b.y}, p2 = {b.z, b.w, c.x};
     *inst_out = f2u(c.y); *prim_out = f2u(c.z);
-    V3 e1 = p1 - p0, e2 = p2 - p0;
-    V3 pvec = cross(d, e2);
-    float det = dot(e1, pvec);
+    const V3 A = tri_permute(p0 - o, R.k0, R.k2), B = tri_permute(p1 - o, R.k0, R.k2), C = tri_permute(p2 - o, R.k0, R.k2);
+    const float Ax = A.x - R.S.x * A.z, Ay = A.y - R.S.y * A.z;
+    const float Bx = B.x - R.S.x * B.z, By = B.y - R.S.y * B.z;
+    const float Cx = C.x - R.S.x * C.z, Cy = C.y - R.S.y * C.z;
+    const float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    // (v_min3 / v_max3: a NaN operand is ignored here and propagated by the oracle's compare-and-select — either way a NaN edge function
+    // ends in a NaN det and a NaN t, which no caller accepts)
+    const float lo = __builtin_fminf(__builtin_fminf(U, V), W), hi = __builtin_fmaxf(__builtin_fmaxf(U, V), W);
+    if (lo < 0.f && hi > 0.f) return false; // the edge functions disagree in sign: outside (zeros are inside for either sign)
+    const float det = U + V + W;
     if (det == 0.f) return false;
-    float inv = 1.f / det;
-    V3 tvec = o - p0;
-    float u = dot(tvec, pvec) * inv;
-    if (!(u >= 0.f && u <= 1.f)) return false;
-    V3 qvec = cross(tvec, e1);
-    float v = dot(d, qvec) * inv;
-    if (!(v >= 0.f && u + v <= 1.f)) return false;
-    *t_out = dot(e2, qvec) * inv;
-    *u_out = u; *v_out = v;
+    // t from the triangle's plane in the unsheared frame (see the oracle's note): interpolated sheared depths are off by eps * |vertex - o|,
+    // more than a spawned ray's offset on a large quad; d' . N = d_z * det, so one reciprocal serves t, u and v
+    const V3 e1 = B - A, e2 = C - A;
+    const V3 N = cross(e2, e1); // this orientation has N . (Sx, Sy, 1) = U + V + W
+    const float inv = 1.f / det;
+    const float t = dot(A, N) * R.S.z * inv;
+    // the hit lies within the triangle's extent along the dominant axis (padded by 2^-14): filters the arbitrary t of a triangle seen
+    // edge-on, which would otherwise be reported or not depending on the order the leaves are visited in (see the oracle's note)
+    const float zlo = __builtin_fminf(__builtin_fminf(A.z, B.z), C.z) * R.S.z, zhi = __builtin_fmaxf(__builtin_fmaxf(A.z, B.z), C.z) * R.S.z;
+    const float tlo = __builtin_fminf(zlo, zhi), thi = __builtin_fmaxf(zlo, zhi);
+    const float pad = 1.f / 16384.f;
+    if (!(t * (1.f + pad) >= tlo && t * (1.f - pad) <= thi)) return false;
+    *t_out = t; *u_out = V * inv; *v_out = W * inv;
     return true;
 }
 
@@ -181,7 +213,8 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
     int32_t pend = kTravDone;        // parked leaf or kTravDone
     int sp = 0;
     int owner = -1;
-    V3 o = mk3(0.f), d = mk3(0.f), inv = mk3(0.f);
+    V3 o = mk3(0.f), inv = mk3(0.f);
+    TriRay tray = {mk3(0.f), false, false}; // the watertight triangle test's view of the ray direction (kept instead of d)
     float t_max = 0.f, best_t = 0.f; // best_t: quad-wide culling bound
     bool anyh = false;
     // lane-local best candidate (merged across the quad when the ray retires)
@@ -261,7 +294,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 float t, u, w;
                 uint32_t inst, prim;
                 if constexpr (COUNT) ++nt;
-                if (intersect_tri(S.tri_pos + first + q, o, d, &t, &u, &w, &inst, &prim) && t > 0.f && t < t_max) {
+                if (intersect_tri(S.tri_pos + first + q, o, tray, &t, &u, &w, &inst, &prim) && t > 0.f && t < t_max) {
                     bool better = !found || t < bt || (t == bt && (inst < binst || (inst == binst && prim < bprim)));
                     if (better) { found = true; bt = t; binst = inst; bprim = prim; btri = first + q; bu = u; bv = w; }
                 }
@@ -304,7 +337,9 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
         const uint32_t base = io.more() ? io.claim((uint32_t) __popcll(idle_mask)) : 0xffffffffu;
         if (idle && base != 0xffffffffu) {
             uint32_t idx = base + (uint32_t) __popcll(idle_mask & ((1ull << (lane & ~3u)) - 1ull));
+            V3 d;
             if (io.load(idx, owner, o, d, t_max, anyh)) {
+                tray = tri_ray_setup(d);
                 // v_rcp_f32 (1 ulp) is enough here: inv only feeds the padded, conservative slab test
                 inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
                 best_t = t_max; cur = S.root; sp = 0;
