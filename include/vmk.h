@@ -333,7 +333,9 @@ int vmk_synchronize(vmk_ctx *ctx);
 int vmk_enable_kernel_timing(vmk_ctx *ctx, int enabled);
 int vmk_collect_kernel_ms(vmk_ctx *ctx, float *out_ms, uint32_t max_count, uint32_t *count);
 int vmk_download_accum(vmk_ctx *ctx, float *out_rgba /* width*height*4 */);
-/* exposure -> tone map -> (optional second tone map + sRGB, Pipeline::final_picture) -> host RGBA float */
+/* exposure -> tone map -> host RGBA float (final_picture 0: the output_buffer of pt.cpp:96-116);  final_picture 1: + the second tone map
+ * and the sRGB curve of Pipeline::final_picture (pipeline.cpp:337-354, postprocessor.cpp:13-30);  2: + the second tone map only, as that
+ * function does for output names ending in "exr" / "hdr" (vmk_host_final_picture_mode picks 1 or 2 from a file name) */
 int vmk_tonemap(vmk_ctx *ctx, int final_picture, float *out_rgba);
 
 int vmk_get_counters(vmk_ctx *ctx, vmk_counters *out);

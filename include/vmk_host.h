@@ -9,8 +9,11 @@
  *                                                                         base/import/node_desc.cpp (defaults),
  *                                                                         base/mgr/scene.cpp:16-35,79-91,165-187
  *   vmk_host_register_image  ocarina Image::load (image_pool.cpp:23-28)   decoded pixels handed in by the caller take precedence;
- *                                                                         otherwise .png (8-bit), baseline .jpg and .hdr are decoded
- *                                                                         natively (csrc/host/image_codec.h)
+ *                                                                         otherwise .png (8-bit), baseline .jpg, .hdr and .exr are decoded
+ *                                                                         natively (csrc/host/image_codec.h, csrc/host/exr.h)
+ *   vmk_host_load_image / vmk_host_save_image / vmk_host_final_picture_mode
+ *                            ocarina Image::load / Image::save_image; Pipeline::save_result + final_picture
+ *                                                                         base/mgr/pipeline.cpp:190-204,337-354
  * Error convention: 0 ok, negative on error, message via vmk_host_last_error() (thread-local).
  */
 #ifndef VMK_HOST_H
@@ -62,6 +65,20 @@ uint32_t vmk_host_output_spp(const vmk_host_scene *scene);    /* output.spp (nod
 const char *vmk_host_output_fn(const vmk_host_scene *scene);  /* output.fn */
 /* one line per plugin object the scene instantiated: "category/type name" (Vision's plugin namespace) */
 const char *vmk_host_describe(const vmk_host_scene *scene);
+
+/* Image files without a scene — ocarina's Image::load / Image::save_image behind src/base/mgr/image_pool.cpp:23-28 and
+ * Pipeline::save_result (src/base/mgr/pipeline.cpp:190-198).  Containers: .png (8-bit, non-interlaced), baseline .jpg, Radiance .hdr and
+ * OpenEXR .exr (single-part scanline; NONE / RLE / ZIPS / ZIP / PIZ; half, float, uint; csrc/host/exr.h) are decoded; .png (8-bit RGB,
+ * value * 255 + 0.5), .exr (float32 B G R, ZIP) and .hdr (RGBE) are written.  Anything else is an error with a message, never a guess.
+ * vmk_host_load_image: interleaved pixels (`channels` of uint8 when *is_float == 0, of float32 otherwise), allocated by the library —
+ * release with vmk_host_free_image. */
+int vmk_host_load_image(const char *path, uint32_t *width, uint32_t *height, uint32_t *channels, int *is_float, void **pixels);
+void vmk_host_free_image(void *pixels);
+/* The save path of Pipeline::save_result without Python:  mode = vmk_host_final_picture_mode(fn)  (1: second tone map + sRGB gamma,
+ * 2: second tone map only — names ending in "exr" / "hdr", pipeline.cpp:337-340);  vmk_tonemap(ctx, mode, rgba);
+ * vmk_host_save_image(fn, width, height, rgba)  (4 floats per pixel, alpha ignored). */
+int vmk_host_final_picture_mode(const char *fn);
+int vmk_host_save_image(const char *path, uint32_t width, uint32_t height, const float *rgba);
 
 /* Regenerate the sRGB -> sigmoid-spectrum coefficient table the hero spectrum uplifts colours with
  * (sRGBToSpectrumTable_Data, hero.cpp:52-76; its header "srgb2spec.h" is not part of the reference checkout) from the CIE

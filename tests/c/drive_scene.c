@@ -1,6 +1,6 @@
 /* drive_scene.c — the whole hot path driven from plain C through include/vmk.h + include/vmk_host.h only (no Python, no C++):
  * load a Vision scene -> hand decoded images over (none needed here) -> upload -> GPU BVH build -> render params -> self check ->
- * render a batch -> download the linear film -> tone map.  What a C / C++ host such as Vision's plugin stub does.
+ * render a batch -> download the linear film -> tone map -> save the picture (.png, .exr).  What a C / C++ host such as Vision's plugin stub does.
  * usage: drive_scene <scene.json> <width> <height> <frames> <out.f32>      (out: width*height*4 float32, the linear film)
  * exit status: 0 ok, 1 usage, 2 any vmk / vmk_host error (message on stderr). */
 #include <stdio.h>
@@ -62,6 +62,14 @@ int main(int argc, char **argv) {
     double mean = 0.0;
     for (size_t i = 0; i < n; i += 4) mean += picture[i] + picture[i + 1] + picture[i + 2];
     printf("final picture mean %.6f\n", mean / (double) (n / 4 * 3));
+    /* Pipeline::save_result (pipeline.cpp:190-204): final_picture -> Image::save_image, for a .png and for an .exr name (no gamma) */
+    char name[4096];
+    snprintf(name, sizeof name, "%s.png", argv[5]);
+    HOST_TRY(vmk_host_save_image(name, params->width, params->height, picture));
+    snprintf(name, sizeof name, "%s.exr", argv[5]);
+    VMK_TRY(vmk_tonemap(ctx, vmk_host_final_picture_mode(name), picture));
+    HOST_TRY(vmk_host_save_image(name, params->width, params->height, picture));
+    printf("saved %s.png and %s.exr\n", argv[5], argv[5]);
     FILE *f = fopen(argv[5], "wb");
     if (!f || fwrite(film, sizeof(float), n, f) != n) { fprintf(stderr, "cannot write %s\n", argv[5]); return 2; }
     fclose(f);

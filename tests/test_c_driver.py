@@ -47,3 +47,11 @@ def test_c_driver_renders_cbox_like_the_oracle(built, tmp_path):
     hs = HostScene(scene, width=48, height=40)
     ref, _ = oracle_py.OracleScene(hs).render(hs.params_copy(), 0, 4)
     assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    # the save path, from C: the PNG is the 8-bit final picture (two tone maps + sRGB), the EXR the float one without the sRGB curve
+    from PIL import Image
+    from vision_amd.host import load_image
+    png = np.asarray(Image.open(out + ".png")).astype(np.float64) / 255.0
+    exr = load_image(out + ".exr").astype(np.float64)
+    assert png.shape == (40, 48, 3) and exr.shape == (40, 48, 3) and "saved" in r.stdout
+    srgb = np.where(exr <= 0.0031308, 12.92 * exr, 1.055 * np.power(np.maximum(exr, 1e-12), 1 / 2.4) - 0.055)
+    assert np.abs(srgb - png).max() < 1.5 / 255.0

@@ -403,3 +403,91 @@ def test_native_decoders_refuse_what_they_do_not_decode(built, tmp_path):
         assert bool(hs.image_paths) == (not native)
         ref = HostScene(path, width=16, height=16, decode="pillow")
         assert C.string_at(hs.scene.tex_data, hs.scene.tex_bytes) == C.string_at(ref.scene.tex_data, ref.scene.tex_bytes), fn
+
+
+# ---- OpenEXR / save path in the C++ host (image_pool.cpp:13-35, pipeline.cpp:190-204,337-354; csrc/host/exr.h, image_codec.h) ----
+def test_exr_decoder_on_the_reference_s_own_files(built):
+    """Two EXR files the reference ships (tools/make_golden_exr.py): res/sky.exr as it is (RGBA half, ZIP) and two PIZ blocks of
+    cbox/TungstenRender.exr.  Pins: (a) this decoder's committed statistics (regression); (b) an independent witness for PIZ — the PNG the
+    reference keeps next to that EXR is the same render through a display curve, so decoded^(1/2.2) must track it pixel by pixel;
+    (c) plausibility of the sky: finite, non-negative, alpha 1, brighter above the horizon than below."""
+    import json
+    from vision_amd.host import load_image
+    G = os.path.join(ROOT, "tests", "golden")
+    exp = json.load(open(os.path.join(G, "exr_expected.json")))
+    for fn, e in exp.items():
+        a = load_image(os.path.join(G, fn))
+        assert a.dtype == np.float32 and list(a.shape) == e["shape"] and np.isfinite(a).all()
+        assert np.allclose(a.astype(np.float64).mean((0, 1)), e["mean"], rtol=1e-12) and float(a.max()) == e["max"] and float(a.min()) == e["min"]
+        for y, x, v in e["probe"]:
+            assert a[y, x].astype(np.float64).tolist() == v
+    sky = load_image(os.path.join(G, "exr_sky_zip_half.exr"))
+    assert (sky >= 0).all() and (sky[..., 3] == 1).all() and sky[:100, :, :3].mean() > 3 * sky[200:, :, :3].mean()
+    box = load_image(os.path.join(G, "exr_cbox_piz_half.exr")).astype(np.float64)
+    png = np.load(os.path.join(G, "exr_cbox_rows.npy")).astype(np.float64) / 255.0
+    enc = np.clip(box, 0, 1) ** (1 / 2.2)
+    assert np.corrcoef(enc.ravel(), png.ravel())[0, 1] > 0.99 and np.abs(enc - png).mean() < 0.06
+
+
+def test_exr_png_hdr_writers_round_trip(built, tmp_path):
+    """vmk_host_save_image: .exr (float32, ZIP) decodes back to the same bits; .png is the 8-bit picture Pillow reads back; .hdr
+    within RGBE precision; the deflate encoder's streams pass both this repo's inflate and Pillow's zlib."""
+    from PIL import Image
+    from vision_amd.host import load_image, save_image, final_picture_mode, HostError
+    rng = np.random.default_rng(5)
+    img = np.zeros((37, 53, 4), np.float32)
+    img[..., :3] = rng.random((37, 53, 3), dtype=np.float32) ** 3 * 4.0
+    img[5:20, 7:30, :3] = 0.25          # flat areas: runs for the LZ77 matcher
+    img[..., 3] = 1.0
+    p = save_image(os.path.join(tmp_path, "a.exr"), img)
+    back = load_image(p)
+    assert back.shape == (37, 53, 3) and np.array_equal(back.view(np.uint32), img[..., :3].copy().view(np.uint32))
+    p = save_image(os.path.join(tmp_path, "a.png"), img)
+    want = (np.clip(img[..., :3], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert np.array_equal(np.asarray(Image.open(p)), want) and np.array_equal(load_image(p), want)
+    p = save_image(os.path.join(tmp_path, "a.hdr"), img)
+    hdr = load_image(p)[..., :3]
+    assert np.abs(hdr - img[..., :3]).max() <= img[..., :3].max() / 128.0
+    assert final_picture_mode("x.png") == 1 and final_picture_mode("dispersion-hero-2000.exr") == 2 and final_picture_mode("a.hdr") == 2
+    with pytest.raises(HostError, match="no encoder"):
+        save_image(os.path.join(tmp_path, "a.bmp"), img)
+    with pytest.raises(HostError, match="cannot open|no decoder"):
+        load_image(os.path.join(tmp_path, "missing.exr"))
+
+
+def test_truncated_and_hostile_image_files_are_errors_not_hangs(built, tmp_path):
+    """A truncated PNG / EXR must fail with a message: the inflate stops as soon as it would have to invent input bits and never grows
+    its output beyond what the container declares (a truncated stream used to decode zeros for ever)."""
+    from PIL import Image
+    from vision_amd.host import load_image, HostError
+    rng = np.random.default_rng(2)
+    Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)).save(os.path.join(tmp_path, "ok.png"))
+    data = open(os.path.join(tmp_path, "ok.png"), "rb").read()
+    # keep the chunk structure valid but cut the IDAT payload short (length + CRC are not checked by the decoder)
+    at = data.index(b"IDAT")
+    ln = int.from_bytes(data[at - 4:at], "big")
+    cut = data[:at - 4] + (ln // 2).to_bytes(4, "big") + data[at:at + 4 + ln // 2] + b"\0\0\0\0" + data[at + 4 + ln + 4:]
+    open(os.path.join(tmp_path, "cut.png"), "wb").write(cut)
+    with pytest.raises(HostError, match="truncated|too short|deflate"):
+        load_image(os.path.join(tmp_path, "cut.png"))
+    exr = open(os.path.join(ROOT, "tests", "golden", "exr_sky_zip_half.exr"), "rb").read()
+    open(os.path.join(tmp_path, "cut.exr"), "wb").write(exr[:len(exr) // 2])
+    with pytest.raises(HostError, match="truncated|beyond"):
+        load_image(os.path.join(tmp_path, "cut.exr"))
+    open(os.path.join(tmp_path, "junk.exr"), "wb").write(b"\x76\x2f\x31\x01" + bytes(64))
+    with pytest.raises(HostError):
+        load_image(os.path.join(tmp_path, "junk.exr"))
+
+
+def test_exr_environment_map_loads_when_present(built, tmp_path):
+    """A scene whose spherical light names an .exr file gets that file (not the procedural stand-in) when it exists."""
+    import shutil
+    sc = _cbox()
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "exr_sky_zip_half.exr"), os.path.join(tmp_path, "sky.exr"))
+    sc["light_sampler"]["param"]["lights"] = [{"type": "spherical", "param": {"color": {"fn": "sky.exr", "color_space": "linear"}, "scale": 1.0,
+                                                                               "o2w": {"type": "Euler", "param": {"yaw": 0}}}}]
+    hs = HostScene(_write(tmp_path, "exr_env.json", sc), width=16, height=16)
+    assert "stand-in" not in hs.description
+    lights = [hs.scene.lights[i] for i in range(hs.scene.n_lights)]
+    env = [l for l in lights if l.type == 1][0]
+    assert (env.res_x, env.res_y) == (512, 256)

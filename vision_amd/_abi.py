@@ -121,4 +121,5 @@ VMK_SYMBOLS = ["vmk_create", "vmk_destroy", "vmk_last_error", "vmk_abi_version",
                "vmk_comm_adopt", "vmk_enable_kernel_timing", "vmk_collect_kernel_ms", "vmk_allreduce_framebuffer", "vmk_allgather_framebuffer", "vmk_comm_synchronize"]
 HOST_SYMBOLS = ["vmk_host_register_image", "vmk_host_clear_images", "vmk_host_list_images", "vmk_host_load_scene",
                 "vmk_host_free_scene", "vmk_host_scene_tables", "vmk_host_render_params", "vmk_host_output_spp",
-                "vmk_host_output_fn", "vmk_host_describe", "vmk_host_last_error", "vmk_host_build_rgb2spec"]
+                "vmk_host_output_fn", "vmk_host_describe", "vmk_host_last_error", "vmk_host_build_rgb2spec",
+                "vmk_host_load_image", "vmk_host_free_image", "vmk_host_final_picture_mode", "vmk_host_save_image"]

@@ -290,7 +290,7 @@ __global__ void k_tonemap(const float4 *accum, float4 *out, uint32_t n, float ex
         x = tone1(tm, x);
         if (final_picture) { // Pipeline::final_picture applies the tone mapper again + sRGB (pipeline.cpp:337-354, postprocessor.cpp:13-30)
             x = tone1(tm, x);
-            x = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(x, 1.f / 2.4f) - 0.055f;
+            if (final_picture == 1) x = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(x, 1.f / 2.4f) - 0.055f; // (2: a name ending in exr / hdr — no gamma, pipeline.cpp:339)
         }
         v[c] = x;
     }

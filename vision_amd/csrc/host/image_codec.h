@@ -1,4 +1,5 @@
-// image_codec.h — native decoders for the image files Vision scenes reference: PNG (8-bit, non-interlaced) and baseline JPEG.
+// image_codec.h — native decoders for the image files Vision scenes reference: PNG (8-bit, non-interlaced) and baseline JPEG — and the
+// encoders of the save path (PNG, Radiance HDR; OpenEXR lives in exr.h).
 // Replaces ocarina Image::load for these two containers (base/mgr/image_pool.cpp:23-28 -> stb / FreeImage in ocarina, absent
 // from the checkout), so a C / C++ host can load a textured scene without handing decoded pixels in (vmk_host_register_image
 // still takes precedence when a host already holds them).  Own implementation of the published formats:
@@ -9,6 +10,8 @@
 //          "fancy" chroma upsampling, 16-bit fixed-point YCbCr->RGB) so that a texture decodes to the same bytes here and in Pillow;
 //          tests/test_host.py compares both on every JPEG the scenes ship.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -22,9 +25,9 @@ struct Decoded { uint32_t w{0}, h{0}, channels{0}; std::vector<uint8_t> px; std:
 // DEFLATE (RFC 1951) inside a zlib stream (RFC 1950)
 // ---------------------------------------------------------------------------------------------------------
 struct BitReader {
-    const uint8_t *p, *end; uint32_t bits{0}; int n{0};
+    const uint8_t *p, *end; uint32_t bits{0}; int n{0}; bool overrun{false}; // overrun: a read had to invent bytes past the end of the input
     BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
-    int get(int k) { while (n < k) { uint32_t byte = p < end ? *p++ : 0u; bits |= byte << n; n += 8; } int v = (int) (bits & ((1u << k) - 1u)); bits >>= k; n -= k; return v; }
+    int get(int k) { while (n < k) { uint32_t byte = 0u; if (p < end) byte = *p++; else overrun = true; bits |= byte << n; n += 8; } int v = (int) (bits & ((1u << k) - 1u)); bits >>= k; n -= k; return v; }
     bool eof() const { return p >= end && n <= 0; }
 };
 struct Huff { // canonical Huffman table: counts per length + symbols in code order
@@ -48,7 +51,10 @@ struct Huff { // canonical Huffman table: counts per length + symbols in code or
         return -1;
     }
 };
-inline bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, std::string &err) {
+// `max_out`: the caller's bound on the decoded size (a PNG's h * (stride + 1), an EXR block's byte count); a stream that decodes to more is
+// refused instead of growing `out` without limit, and a stream that runs past its last byte (truncated / corrupt input) is an error as soon
+// as the reader has to invent bits, not only when the bit counter happens to be empty.
+inline bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, std::string &err, size_t max_out = (size_t) -1) {
     if (in.size() < 6 || (in[0] & 0x0f) != 8 || ((in[0] << 8) | in[1]) % 31 != 0 || (in[1] & 0x20)) { err = "bad zlib header"; return false; }
     BitReader br(in.data() + 2, in.data() + in.size());
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -62,6 +68,7 @@ inline bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &o
             if (br.end - br.p < 4) { err = "truncated stored block"; return false; }
             uint32_t len = br.p[0] | (br.p[1] << 8), nlen = br.p[2] | (br.p[3] << 8); br.p += 4;
             if ((len ^ 0xffffu) != nlen || (size_t) (br.end - br.p) < len) { err = "bad stored block"; return false; }
+            if (out.size() + len > max_out) { err = "deflate stream decodes to more than the container allows"; return false; }
             out.insert(out.end(), br.p, br.p + len); br.p += len;
         } else if (type == 1 || type == 2) {
             Huff hl, hd;
@@ -100,7 +107,8 @@ inline bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &o
             for (;;) {
                 int sym = hl.decode(br);
                 if (sym < 0) { err = "bad literal/length code"; return false; }
-                if (sym < 256) out.push_back((uint8_t) sym);
+                if (br.overrun) { err = "truncated deflate stream"; return false; }
+                if (sym < 256) { if (out.size() >= max_out) { err = "deflate stream decodes to more than the container allows"; return false; } out.push_back((uint8_t) sym); }
                 else if (sym == 256) break;
                 else {
                     sym -= 257;
@@ -110,12 +118,14 @@ inline bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> &o
                     if (ds < 0 || ds >= 30) { err = "bad distance symbol"; return false; }
                     size_t dist = dbase[ds] + (size_t) br.get(dext[ds]);
                     if (dist > out.size()) { err = "distance beyond output"; return false; }
+                    if (out.size() + (size_t) len > max_out) { err = "deflate stream decodes to more than the container allows"; return false; }
                     size_t from = out.size() - dist;
                     for (int i = 0; i < len; ++i) out.push_back(out[from + i]);
                 }
                 if (br.p >= br.end && br.n <= 0 && !last) { err = "truncated deflate stream"; return false; }
             }
         } else { err = "bad block type"; return false; }
+        if (br.overrun) { err = "truncated deflate stream"; return false; }
         if (last) break;
         if (br.p >= br.end && br.n <= 0) { err = "truncated deflate stream"; return false; }
     }
@@ -152,8 +162,9 @@ inline Decoded decode_png(const std::vector<uint8_t> &f) {
     int spp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!spp || (ctype == 3 && plte.size() < 3)) { d.error = "bad PNG colour type"; return d; }
     std::vector<uint8_t> raw;
-    raw.reserve((size_t) h * ((size_t) w * spp + 1));
-    if (!inflate_zlib(idat, raw, d.error)) return d;
+    const size_t expect = (size_t) h * ((size_t) w * spp + 1);
+    raw.reserve(std::min(expect, idat.size() * 1032 + 64)); // (deflate expands by at most 1032x: nothing is reserved on the IHDR's word alone)
+    if (!inflate_zlib(idat, raw, d.error, expect)) return d;
     const size_t stride = (size_t) w * spp;
     if (raw.size() < (stride + 1) * h) { d.error = "PNG data too short"; return d; }
     std::vector<uint8_t> img(stride * h);
@@ -368,6 +379,120 @@ inline Decoded decode_jpeg(const std::vector<uint8_t> &f) {
         d.px[i * 3] = (uint8_t) (r < 0 ? 0 : r > 255 ? 255 : r); d.px[i * 3 + 1] = (uint8_t) (g < 0 ? 0 : g > 255 ? 255 : g); d.px[i * 3 + 2] = (uint8_t) (b < 0 ? 0 : b > 255 ? 255 : b);
     }
     return d;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// encoders (Image::save_image of the reference goes through ocarina / stb, absent): DEFLATE, PNG, Radiance HDR
+// ---------------------------------------------------------------------------------------------------------
+inline uint32_t crc32(const uint8_t *p, size_t n, uint32_t crc = 0) {
+    static uint32_t table[256]; static bool init = false;
+    if (!init) { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return ~crc;
+}
+inline uint32_t adler32(const uint8_t *p, size_t n) {
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < n; ++i) { a = (a + p[i]) % 65521u; b = (b + a) % 65521u; }
+    return (b << 16) | a;
+}
+// zlib stream with ONE fixed-Huffman block: greedy LZ77 over a 32 KiB window with a hash of 3-byte prefixes (chains of 32)
+inline std::vector<uint8_t> deflate_zlib(const uint8_t *in, size_t n) {
+    std::vector<uint8_t> out = {0x78, 0x01};
+    uint32_t acc = 0; int nb = 0;
+    auto put = [&](uint32_t v, int k) { acc |= v << nb; nb += k; while (nb >= 8) { out.push_back((uint8_t) acc); acc >>= 8; nb -= 8; } };
+    auto put_rev = [&](uint32_t code, int k) { uint32_t r = 0; for (int i = 0; i < k; ++i) r |= ((code >> i) & 1u) << (k - 1 - i); put(r, k); }; // Huffman codes go MSB first
+    auto lit = [&](int s) { if (s < 144) put_rev(0x30 + s, 8); else if (s < 256) put_rev(0x190 + s - 144, 9); else if (s < 280) put_rev(s - 256, 7); else put_rev(0xc0 + s - 280, 8); };
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    put(1, 1); put(1, 2); // last block, fixed Huffman
+    constexpr int HB = 15;
+    std::vector<int32_t> head((size_t) 1 << HB, -1), prev(n, -1);
+    auto hash = [&](size_t i) { return (uint32_t) ((in[i] * 2654435761u + in[i + 1] * 40503u + in[i + 2] * 2246822519u) >> (32 - HB)); };
+    size_t i = 0;
+    while (i < n) {
+        int best_len = 0; size_t best_dist = 0;
+        if (i + 3 <= n) {
+            uint32_t h = hash(i);
+            int32_t c = head[h]; int chain = 32;
+            while (c >= 0 && chain-- && i - (size_t) c <= 32768) {
+                int l = 0; const size_t lim = std::min<size_t>(258, n - i);
+                while ((size_t) l < lim && in[c + l] == in[i + l]) ++l;
+                if (l > best_len) { best_len = l; best_dist = i - (size_t) c; if (l == 258) break; }
+                c = prev[(size_t) c];
+            }
+        }
+        if (best_len >= 3) {
+            int ls = 28; while (lbase[ls] > best_len) --ls;
+            lit(257 + ls); put((uint32_t) (best_len - lbase[ls]), lext[ls]);
+            int ds = 29; while (dbase[ds] > best_dist) --ds;
+            put_rev((uint32_t) ds, 5); put((uint32_t) (best_dist - dbase[ds]), dext[ds]);
+            for (int k = 0; k < best_len; ++k, ++i) if (i + 3 <= n) { uint32_t h = hash(i); prev[i] = head[h]; head[h] = (int32_t) i; }
+        } else {
+            lit(in[i]);
+            if (i + 3 <= n) { uint32_t h = hash(i); prev[i] = head[h]; head[h] = (int32_t) i; }
+            ++i;
+        }
+    }
+    lit(256);
+    if (nb) put(0, 8 - nb);
+    const uint32_t ad = adler32(in, n);
+    for (int k = 3; k >= 0; --k) out.push_back((uint8_t) (ad >> (8 * k)));
+    return out;
+}
+// 8-bit PNG, colour type 2 (RGB) or 6 (RGBA); every row takes the filter (none / sub / up / paeth) with the smallest sum of |residual|
+inline std::vector<uint8_t> encode_png(uint32_t w, uint32_t h, int channels, const uint8_t *px) {
+    const size_t stride = (size_t) w * channels;
+    std::vector<uint8_t> raw; raw.reserve((stride + 1) * h);
+    std::vector<uint8_t> cand[4]; for (auto &c : cand) c.resize(stride);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t *cur = px + stride * y, *up = y ? cur - stride : nullptr;
+        long best = -1; int bi = 0;
+        for (int ft = 0; ft < 4; ++ft) {
+            long sum = 0;
+            for (size_t x = 0; x < stride; ++x) {
+                int a = x >= (size_t) channels ? cur[x - channels] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t) channels) ? up[x - channels] : 0, pr = 0;
+                if (ft == 1) pr = a; else if (ft == 2) pr = b;
+                else if (ft == 3) { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+                uint8_t r = (uint8_t) (cur[x] - pr); cand[ft][x] = r; sum += r < 128 ? r : 256 - r;
+            }
+            if (best < 0 || sum < best) { best = sum; bi = ft; }
+        }
+        raw.push_back((uint8_t) (bi == 3 ? 4 : bi));
+        raw.insert(raw.end(), cand[bi].begin(), cand[bi].end());
+    }
+    std::vector<uint8_t> f = {0x89, 'P', 'N', 'G', 13, 10, 26, 10};
+    auto chunk = [&](const char *type, const std::vector<uint8_t> &data) {
+        uint32_t len = (uint32_t) data.size();
+        for (int k = 3; k >= 0; --k) f.push_back((uint8_t) (len >> (8 * k)));
+        size_t at = f.size();
+        f.insert(f.end(), type, type + 4); f.insert(f.end(), data.begin(), data.end());
+        uint32_t crc = crc32(f.data() + at, 4 + data.size());
+        for (int k = 3; k >= 0; --k) f.push_back((uint8_t) (crc >> (8 * k)));
+    };
+    std::vector<uint8_t> ihdr(13);
+    for (int k = 0; k < 4; ++k) { ihdr[k] = (uint8_t) (w >> (8 * (3 - k))); ihdr[4 + k] = (uint8_t) (h >> (8 * (3 - k))); }
+    ihdr[8] = 8; ihdr[9] = channels == 4 ? 6 : 2; ihdr[10] = ihdr[11] = ihdr[12] = 0;
+    chunk("IHDR", ihdr);
+    chunk("IDAT", deflate_zlib(raw.data(), raw.size()));
+    chunk("IEND", {});
+    return f;
+}
+// Radiance RGBE, flat (no run-length) scanlines
+inline std::vector<uint8_t> encode_hdr(uint32_t w, uint32_t h, const float *rgba) {
+    std::string head = "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " + std::to_string(h) + " +X " + std::to_string(w) + "\n";
+    std::vector<uint8_t> f(head.begin(), head.end());
+    for (size_t i = 0; i < (size_t) w * h; ++i) {
+        const float r = rgba[i * 4], g = rgba[i * 4 + 1], b = rgba[i * 4 + 2];
+        float m = std::max(r, std::max(g, b));
+        if (!(m > 1e-32f)) { f.insert(f.end(), {0, 0, 0, 0}); continue; }
+        int e; float s = std::frexp(m, &e) * 256.f / m;
+        f.push_back((uint8_t) std::max(0.f, r * s)); f.push_back((uint8_t) std::max(0.f, g * s)); f.push_back((uint8_t) std::max(0.f, b * s)); f.push_back((uint8_t) (e + 128));
+    }
+    return f;
 }
 
 }// namespace vmk_img

@@ -10,6 +10,7 @@
 #include "../../../include/vmk_host.h"
 #include "json.h"
 #include "image_codec.h"
+#include "exr.h"
 #include "rgb2spec_opt.h"
 
 #include <algorithm>
@@ -296,6 +297,14 @@ struct HostScene {
         auto reg = g_images.find(path);
         if (reg != g_images.end()) img = &reg->second;
         else if (ends_with(fn, ".hdr") && load_hdr(path, local)) img = &local;
+        else if (ends_with(fn, ".exr") && file_exists(path)) { // native OpenEXR (exr.h): scanline, NONE / RLE / ZIPS / ZIP / PIZ, half / float
+            std::ifstream fi(path, std::ios::binary);
+            std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
+            vmk_exr::ImageF dec = vmk_exr::decode(bytes);
+            if (!dec.error.empty()) fail("image '" + path + "': " + dec.error + " (decode it in the caller and hand the pixels to vmk_host_register_image)");
+            local.w = dec.w; local.h = dec.h; local.channels = dec.channels; local.is_float = true; local.f32.swap(dec.px);
+            img = &local;
+        }
         else if ((ends_with(fn, ".png") || ends_with(fn, ".jpg") || ends_with(fn, ".jpeg")) && file_exists(path)) { // native decode (image_codec.h)
             std::ifstream fi(path, std::ios::binary);
             std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
@@ -1286,6 +1295,72 @@ const vmk_render_params *vmk_host_render_params(const vmk_host_scene *scene) { r
 uint32_t vmk_host_output_spp(const vmk_host_scene *scene) { return scene ? scene->hs.output_spp : 0; }
 const char *vmk_host_output_fn(const vmk_host_scene *scene) { return scene ? scene->hs.output_fn.c_str() : ""; }
 const char *vmk_host_describe(const vmk_host_scene *scene) { return scene ? scene->hs.description.c_str() : ""; }
+
+// ---- image files without a scene: Image::load / Image::save_image of the reference (ocarina; image_pool.cpp:23-28, pipeline.cpp:190-198) ----
+static bool read_file(const std::string &path, std::vector<uint8_t> &bytes) {
+    std::ifstream fi(path, std::ios::binary);
+    if (!fi) return false;
+    bytes.assign((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
+    return true;
+}
+int vmk_host_load_image(const char *path, uint32_t *width, uint32_t *height, uint32_t *channels, int *is_float, void **pixels) {
+    if (!path || !width || !height || !channels || !is_float || !pixels) { g_error = "vmk_host_load_image: bad argument"; return VMK_ERR_ARG; }
+    try {
+        const std::string fn = path;
+        std::vector<uint8_t> bytes;
+        const void *src = nullptr; size_t n_bytes = 0;
+        Image hdr; vmk_img::Decoded dec; vmk_exr::ImageF ex;
+        if (ends_with(fn, ".hdr")) {
+            if (!load_hdr(fn, hdr)) throw std::runtime_error("cannot decode '" + fn + "' as Radiance .hdr");
+            *width = hdr.w; *height = hdr.h; *channels = hdr.f32.size() == (size_t) hdr.w * hdr.h * 4 ? 4u : hdr.channels; *is_float = 1; src = hdr.f32.data(); n_bytes = hdr.f32.size() * 4;
+        } else {
+            if (!read_file(fn, bytes)) throw std::runtime_error("cannot open '" + fn + "'");
+            if (ends_with(fn, ".exr")) {
+                ex = vmk_exr::decode(bytes);
+                if (!ex.error.empty()) throw std::runtime_error(fn + ": " + ex.error);
+                *width = ex.w; *height = ex.h; *channels = ex.channels; *is_float = 1; src = ex.px.data(); n_bytes = ex.px.size() * 4;
+            } else if (ends_with(fn, ".png") || ends_with(fn, ".jpg") || ends_with(fn, ".jpeg")) {
+                dec = ends_with(fn, ".png") ? vmk_img::decode_png(bytes) : vmk_img::decode_jpeg(bytes);
+                if (!dec.error.empty()) throw std::runtime_error(fn + ": " + dec.error);
+                *width = dec.w; *height = dec.h; *channels = dec.channels; *is_float = 0; src = dec.px.data(); n_bytes = dec.px.size();
+            } else throw std::runtime_error("'" + fn + "': no decoder for this container (.png .jpg .hdr .exr)");
+        }
+        void *out = std::malloc(n_bytes ? n_bytes : 1);
+        if (!out) throw std::runtime_error("out of memory");
+        std::memcpy(out, src, n_bytes);
+        *pixels = out;
+        return VMK_OK;
+    } catch (std::exception &e) { g_error = std::string("vmk_host_load_image: ") + e.what(); return VMK_ERR_ARG; }
+}
+void vmk_host_free_image(void *pixels) { std::free(pixels); }
+
+int vmk_host_final_picture_mode(const char *fn) { // Pipeline::final_picture (pipeline.cpp:337-340): gamma unless the name ends with exr / hdr
+    const std::string f = fn ? fn : "";
+    return (ends_with(f, "exr") || ends_with(f, "hdr")) ? 2 : 1;
+}
+int vmk_host_save_image(const char *path, uint32_t width, uint32_t height, const float *rgba) {
+    if (!path || !rgba || !width || !height) { g_error = "vmk_host_save_image: bad argument"; return VMK_ERR_ARG; }
+    try {
+        const std::string fn = path;
+        std::vector<uint8_t> bytes;
+        if (ends_with(fn, ".exr")) bytes = vmk_exr::encode(width, height, rgba, 3, false, true); // float32 B G R, ZIP
+        else if (ends_with(fn, ".hdr")) bytes = vmk_img::encode_hdr(width, height, rgba);
+        else if (ends_with(fn, ".png")) {
+            std::vector<uint8_t> px((size_t) width * height * 3);
+            for (size_t i = 0; i < (size_t) width * height; ++i) for (int c = 0; c < 3; ++c) {
+                float v = rgba[i * 4 + c];
+                v = v != v ? 0.f : std::min(1.f, std::max(0.f, v));
+                px[i * 3 + c] = (uint8_t) (v * 255.f + 0.5f);
+            }
+            bytes = vmk_img::encode_png(width, height, 3, px.data());
+        } else throw std::runtime_error("'" + fn + "': no encoder for this container (.png .exr .hdr)");
+        std::ofstream fo(fn, std::ios::binary);
+        if (!fo) throw std::runtime_error("cannot write '" + fn + "'");
+        fo.write((const char *) bytes.data(), (std::streamsize) bytes.size());
+        if (!fo) throw std::runtime_error("short write to '" + fn + "'");
+        return VMK_OK;
+    } catch (std::exception &e) { g_error = std::string("vmk_host_save_image: ") + e.what(); return VMK_ERR_ARG; }
+}
 
 int vmk_host_build_rgb2spec(const char *spectra_path, const char *out_path, uint32_t threads) {
     if (!spectra_path || !out_path) { g_error = "vmk_host_build_rgb2spec: bad argument"; return VMK_ERR_ARG; }

@@ -62,7 +62,7 @@ def register_images_for(json_path):
         if not os.path.exists(p) or p.lower().endswith(".hdr"):
             continue  # missing (stand-in handled by the host) or natively decoded
         if p.lower().endswith(".exr"):
-            continue  # no EXR decoder in this image; host falls back to the procedural stand-in if allowed
+            continue  # decoded natively by the C++ host (csrc/host/exr.h)
         from PIL import Image
         im = Image.open(p)
         if im.mode not in ("L", "RGB", "RGBA"):
@@ -73,6 +73,39 @@ def register_images_for(json_path):
         if rc != 0:
             raise HostError(_err())
     return paths
+
+
+def load_image(path):
+    """vmk_host_load_image: decode .png / .jpg / .hdr / .exr natively (C++ host); returns an array [H, W, C] (uint8 or float32)."""
+    L = lib()
+    L.vmk_host_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    L.vmk_host_free_image.argtypes = [C.c_void_p]
+    w, h, ch, fl, px = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int(), C.c_void_p()
+    if L.vmk_host_load_image(os.fsencode(path), C.byref(w), C.byref(h), C.byref(ch), C.byref(fl), C.byref(px)) != 0:
+        raise HostError(_err())
+    try:
+        n = w.value * h.value * ch.value
+        buf = C.string_at(px, n * (4 if fl.value else 1))
+    finally:
+        L.vmk_host_free_image(px)
+    return np.frombuffer(buf, np.float32 if fl.value else np.uint8).reshape(h.value, w.value, ch.value).copy()
+
+
+def save_image(path, rgba):
+    """vmk_host_save_image: write float RGBA [H, W, 4] as .png (8-bit), .exr (float32, ZIP) or .hdr (RGBE) — Image::save_image of the reference."""
+    L = lib()
+    L.vmk_host_save_image.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    a = np.ascontiguousarray(rgba, np.float32)
+    assert a.ndim == 3 and a.shape[2] == 4
+    if L.vmk_host_save_image(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p)) != 0:
+        raise HostError(_err())
+    return path
+
+
+def final_picture_mode(fn):
+    L = lib()
+    L.vmk_host_final_picture_mode.argtypes = [C.c_char_p]
+    return int(L.vmk_host_final_picture_mode(os.fsencode(fn)))
 
 
 class HostScene:

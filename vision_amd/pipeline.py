@@ -166,19 +166,21 @@ class Pipeline:
     def counters(self):
         return self.backend.counters()
 
-    def final_picture(self):
-        return self.frame_buffer.tone_mapped(final_picture=True)
+    def final_picture(self, fn=None):
+        """Pipeline::final_picture (pipeline.cpp:337-354): the tone-mapped output buffer through the tone mapper a second time, and
+        through the sRGB curve unless the output name ends in exr / hdr."""
+        from .host import final_picture_mode
+        return self.backend.tonemap(final_picture_mode(fn) if fn else 1)
 
     def save_result(self, fn=None):
-        """Pipeline::save_result (pipeline.cpp:190-204): 8-bit PNG of final_picture, or raw .npy for a linear dump."""
+        """Pipeline::save_result (pipeline.cpp:190-204): final_picture -> Image::save_image, both in the C++ host / on the device
+        (vmk_tonemap + vmk_host_save_image: 8-bit PNG, float32 OpenEXR, Radiance HDR).  A ".npy" name dumps the linear buffer."""
+        from .host import save_image
         fn = fn or self.host_scene.output_fn
         if fn.endswith(".npy"):
             np.save(fn, self.frame_buffer.download())
             return fn
-        from PIL import Image
-        img = np.clip(self.final_picture()[..., :3], 0.0, 1.0)
-        Image.fromarray((img * 255.0 + 0.5).astype(np.uint8)).save(fn)
-        return fn
+        return save_image(fn, self.final_picture(fn))
 
     def close(self):
         if getattr(self, "backend", None):
