@@ -70,25 +70,29 @@ VD TriRay tri_ray_setup(V3 d) {
     r.S.z = 1.f / dp.z; r.S.x = dp.x * r.S.z; r.S.y = dp.y * r.S.z;
     return r;
 }
-VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, const TriRay &R, float *t_out, float *u_out, float *v_out, uint32_t *inst_out, uint32_t *prim_out) {
-    // 48 B record as three 16 B loads
-    const float4 *q = reinterpret_cast<const float4 *>(tp);
-    float4 a = ldg(q), b = ldg(q + 1), c = ldg(q + 2);
+VD bool intersect_tri(const vmk_tri_pos *tris, uint32_t index, V3 o, const TriRay &R, float *t_out, float *u_out, float *v_out, uint32_t *inst_out, uint32_t *prim_out) {
+    // 48 B record as three 16 B loads at "scalar base + 32-bit offset" (vmk_build_accel checks n_tris * 48 < 4 GiB): no 64-bit address
+    // arithmetic and no address register pair to keep (it used to be spilled and reloaded from scratch in front of every leaf)
+    const uint32_t off = index * (uint32_t) sizeof(vmk_tri_pos);
+    float4 a = ldg_off(tris, off), b = ldg_off(tris, off + 16u), c = ldg_off(tris, off + 32u);
     V3 p0 = {a.x, a.y, a.z}, p1 = {a.w, b.x, b.y}, p2 = {b.z, b.w, c.x};
     *inst_out = f2u(c.y); *prim_out = f2u(c.z);
     const V3 A = tri_permute(p0 - o, R.k0, R.k2), B = tri_permute(p1 - o, R.k0, R.k2), C = tri_permute(p2 - o, R.k0, R.k2);
-    const float Ax = A.x - R.S.x * A.z, Ay = A.y - R.S.y * A.z;
-    const float Bx = B.x - R.S.x * B.z, By = B.y - R.S.y * B.z;
-    const float Cx = C.x - R.S.x * C.z, Cy = C.y - R.S.y * C.z;
-    const float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    // (packed fp32: the shear of a vertex and the two products of an edge function are one v_pk_mul_f32 / v_pk_add_f32 each — the same
+    // IEEE operations in the same order as the scalar form the oracle runs, so the bits do not change)
+    const f2v Sxy = {R.S.x, R.S.y};
+    const f2v Axy = f2v{A.x, A.y} - Sxy * A.z, Bxy = f2v{B.x, B.y} - Sxy * B.z, Cxy = f2v{C.x, C.y} - Sxy * C.z;
+    const f2v pu = Cxy * f2v{Bxy.y, Bxy.x}, pv = Axy * f2v{Cxy.y, Cxy.x}, pw = Bxy * f2v{Axy.y, Axy.x};
+    const float U = pu.x - pu.y, V = pv.x - pv.y, W = pw.x - pw.y; // Cx By - Cy Bx,  Ax Cy - Ay Cx,  Bx Ay - By Ax
     // (v_min3 / v_max3: a NaN operand is ignored here and propagated by the oracle's compare-and-select — either way a NaN edge function
     // ends in a NaN det and a NaN t, which no caller accepts)
     const float lo = __builtin_fminf(__builtin_fminf(U, V), W), hi = __builtin_fmaxf(__builtin_fmaxf(U, V), W);
-    if (lo < 0.f && hi > 0.f) return false; // the edge functions disagree in sign: outside (zeros are inside for either sign)
+    const bool inside = !(lo < 0.f && hi > 0.f); // the edge functions agree in sign (zeros are inside for either sign)
     const float det = U + V + W;
-    if (det == 0.f) return false;
     // t from the triangle's plane in the unsheared frame (see the oracle's note): interpolated sheared depths are off by eps * |vertex - o|,
-    // more than a spawned ray's offset on a large quad; d' . N = d_z * det, so one reciprocal serves t, u and v
+    // more than a spawned ray's offset on a large quad; d' . N = d_z * det, so one reciprocal serves t, u and v.
+    // Straight-line code: the oracle's early returns (outside, det == 0, t out of range) are folded into ONE predicate — a det of 0 makes
+    // inv infinite and t infinite or NaN, which fails the range test below like everything else that is not a hit.
     const V3 e1 = B - A, e2 = C - A;
     const V3 N = cross(e2, e1); // this orientation has N . (Sx, Sy, 1) = U + V + W
     const float inv = 1.f / det;
@@ -96,11 +100,10 @@ VD bool intersect_tri(const vmk_tri_pos *tp, V3 o, const TriRay &R, float *t_out
     // the hit lies within the triangle's extent along the dominant axis (padded by 2^-14): filters the arbitrary t of a triangle seen
     // edge-on, which would otherwise be reported or not depending on the order the leaves are visited in (see the oracle's note)
     const float zlo = __builtin_fminf(__builtin_fminf(A.z, B.z), C.z) * R.S.z, zhi = __builtin_fmaxf(__builtin_fmaxf(A.z, B.z), C.z) * R.S.z;
-    const float tlo = __builtin_fminf(zlo, zhi), thi = __builtin_fmaxf(zlo, zhi);
+    const float tlo = zlo < zhi ? zlo : zhi, thi = zlo < zhi ? zhi : zlo;
     const float pad = 1.f / 16384.f;
-    if (!(t * (1.f + pad) >= tlo && t * (1.f - pad) <= thi)) return false;
     *t_out = t; *u_out = V * inv; *v_out = W * inv;
-    return true;
+    return inside && det != 0.f && t * (1.f + pad) >= tlo && t * (1.f - pad) <= thi;
 }
 
 // conservative slab test; NaN slabs (0 * inf) are ignored by the min/max (IEEE minNum/maxNum on v_min/v_max_f32).
@@ -205,7 +208,11 @@ struct GlobalRayIO {
 // the same (deterministic) rays.
 // DEEP: the tree's worst-case stack need exceeds the LDS stack — entries beyond it live in HBM (see kStackOverflow).  A compile-time
 // variant: the test on every push / pop costs the hot kernel 8 % on classroom when it is there unconditionally.
-template<class IO, bool COUNT = true, bool DEEP = false>
+// ANYHIT: every ray of the call is an occlusion query (the shadow traversal of path_bounce, k_trace with any_hit).  A compile-time
+// variant because such rays need none of the closest-hit machinery and the loop is VALU-issue bound: the children of a node are not
+// ranked by distance (any hit ends the ray: the quad's hit mask from one ballot places the pushes), no candidate (t, u, v, inst, prim)
+// is kept or merged, and the culling bound never tightens.
+template<class IO, bool COUNT = true, bool DEEP = false, bool ANYHIT = false>
 VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, uint32_t *n_rays) {
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
     // ---- per-quad traversal state, replicated in the quad's 4 lanes ----
@@ -245,23 +252,42 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 // everywhere, from walking into them)
                 bool h = hit_box(f2v{a.x, a.y}, f2v{a.z, a.w}, f2v{b.x, b.y}, o, inv, best_t, &tn) && ref != kEmptyRef;
                 if constexpr (COUNT) nn += q == 0 ? 1u : 0u;
+                int rank, n;
+                int32_t cand;
+                uint32_t key = 0, k1 = 0, k2 = 0, k3 = 0;
+                if constexpr (ANYHIT) {
+                    // no order among the children: the quad's 4-bit hit mask (one ballot) gives the count, the child to descend into (the
+                    // highest hit lane) and every other hit lane's place on the stack
+                    const uint32_t hits = (uint32_t) (__ballot(h) >> (lane & ~3u)) & 0xfu;
+                    n = __popc(hits);
+                    const int top = 31 - __clz((int) hits);         // -1 when no child is hit
+                    rank = (int) q == top ? 0 : 1 + __popc(hits & ((1u << q) - 1u)); // 1 .. n-1 for the others, in lane order
+                    cand = (h && rank == 0) ? ref : (int32_t) 0x80000000;
+                    cand = max(cand, quad_perm_i<kQuadXor1>(cand));
+                    cand = max(cand, quad_perm_i<kQuadXor2>(cand));
+                } else {
                 // order key: entry distance (non-negative float bits order like integers) with the lane id in the two low
                 // mantissa bits, so keys are distinct and three unsigned compares rank the children; misses sort last.  The
                 // visiting order only steers culling, it never changes which hit is returned.
-                uint32_t key = h ? ((f2u(tn) & ~3u) | q) : 0xffffffffu;
-                uint32_t k1 = (uint32_t) quad_perm_i<kQuadXor1>((int32_t) key), k2 = (uint32_t) quad_perm_i<kQuadXor2>((int32_t) key), k3 = (uint32_t) quad_perm_i<kQuadXor3>((int32_t) key);
-                int rank = (k1 < key ? 1 : 0) + (k2 < key ? 1 : 0) + (k3 < key ? 1 : 0);
-                int n = h ? 1 : 0;
+                key = h ? ((f2u(tn) & ~3u) | q) : 0xffffffffu;
+                k1 = (uint32_t) quad_perm_i<kQuadXor1>((int32_t) key); k2 = (uint32_t) quad_perm_i<kQuadXor2>((int32_t) key); k3 = (uint32_t) quad_perm_i<kQuadXor3>((int32_t) key);
+                rank = (k1 < key ? 1 : 0) + (k2 < key ? 1 : 0) + (k3 < key ? 1 : 0);
+                n = h ? 1 : 0;
                 n += quad_perm_i<kQuadXor1>(n);
                 n += quad_perm_i<kQuadXor2>(n);
-                int32_t cand = (h && rank == 0) ? ref : (int32_t) 0x80000000;
+                cand = (h && rank == 0) ? ref : (int32_t) 0x80000000;
                 cand = max(cand, quad_perm_i<kQuadXor1>(cand));
                 cand = max(cand, quad_perm_i<kQuadXor2>(cand));
+                }
                 if (h && rank > 0) { // far children: the nearest of them ends up on top
                     int slot = sp + (n - 1 - rank);
                     if (slot < kQuadStack) ws->stack[slot][quad] = (uint32_t) ref;
                 }
                 if constexpr (DEEP) if (sp + n - 1 > kQuadStack && ovf) { // cold: some of the far children land beyond the LDS stack (deep trees only)
+                    if constexpr (ANYHIT) { // the same placement expressed as keys: rank 0 for the child descended into, then lane order
+                        key = h ? (uint32_t) rank * 4u + q : 0xffffffffu;
+                        k1 = (uint32_t) quad_perm_i<kQuadXor1>((int32_t) key); k2 = (uint32_t) quad_perm_i<kQuadXor2>((int32_t) key); k3 = (uint32_t) quad_perm_i<kQuadXor3>((int32_t) key);
+                    }
                     const int32_t r1 = quad_perm_i<kQuadXor1>(ref), r2 = quad_perm_i<kQuadXor2>(ref), r3 = quad_perm_i<kQuadXor3>(ref);
                     const uint32_t kk[4] = {key, k1, k2, k3};
                     const int32_t rr[4] = {ref, r1, r2, r3};
@@ -294,17 +320,26 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 float t, u, w;
                 uint32_t inst, prim;
                 if constexpr (COUNT) ++nt;
-                if (intersect_tri(S.tri_pos + first + q, o, tray, &t, &u, &w, &inst, &prim) && t > 0.f && t < t_max) {
-                    bool better = !found || t < bt || (t == bt && (inst < binst || (inst == binst && prim < bprim)));
-                    if (better) { found = true; bt = t; binst = inst; bprim = prim; btri = first + q; bu = u; bv = w; }
+                if (intersect_tri(S.tri_pos, first + q, o, tray, &t, &u, &w, &inst, &prim) && t > 0.f && t < t_max) {
+                    if constexpr (ANYHIT) found = true;
+                    else {
+                        bool better = !found || t < bt || (t == bt && (inst < binst || (inst == binst && prim < bprim)));
+                        if (better) { found = true; bt = t; binst = inst; bprim = prim; btri = first + q; bu = u; bv = w; }
+                    }
                 }
             }
-            float m = found ? bt : t_max;
-            m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
-            m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
-            best_t = m;
             pend = kTravDone;
-            if (anyh && m < t_max) cur = kTravDone; // occlusion query: some lane of the quad has a hit
+            if constexpr (ANYHIT) {
+                // occlusion query: one hit in the quad ends the ray (the flag is quad-uniform from here on)
+                found = ((uint32_t) (__ballot(found) >> (lane & ~3u)) & 0xfu) != 0u;
+                if (found) cur = kTravDone;
+            } else {
+                float m = found ? bt : t_max;
+                m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
+                m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
+                best_t = m;
+                if (anyh && m < t_max) cur = kTravDone; // (an occlusion query in a mixed pool: some lane of the quad has a hit)
+            }
         }
         if (cur < 0) { pend = cur; VMK_POP(); } // a second leaf was waiting: park it for the next leaf phase
         // ================= hand back hits, take new rays =================
@@ -314,7 +349,8 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
         const bool any_busy = __any(!idle);
         if (want_mask == 0) { if (!any_busy) break; continue; }
         if (any_busy && __popcll(want_mask) < 4 * VMK_REFILL_QUADS_MIN) continue;
-        if (idle && owner >= 0) {
+        if constexpr (ANYHIT) { if (idle && owner >= 0) { if (q == 0) io.store(owner, found, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); owner = -1; } }
+        else if (idle && owner >= 0) {
             // ---- retire: the lane that holds the quad's best candidate (min t, then inst, then prim) returns it ----
             float m = found ? bt : __builtin_inff();
             m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
@@ -356,8 +392,9 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
 // Trace the rays of all lanes of the wave.  EVERY lane of the wave must call this (convergently); `active` says whether
 // the lane has a ray.  any_hit rays stop at the first valid hit (occlusion query), the others return the closest hit.
 // Returns found; `hit` is filled for closest-hit rays.
-template<bool COUNT = true, bool DEEP = false>
-VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, WaveScratch *ws, Hit &hit, DCounters &cnt) {
+template<bool COUNT = true, bool DEEP = false, bool ANYHIT = false>
+VD bool traverse_wave(const DScene &S, const Ray &r, bool active, WaveScratch *ws, Hit &hit, DCounters &cnt) {
+    constexpr bool any_hit = ANYHIT;
     const uint32_t lane = threadIdx.x & 63u;
     hit.inst = VMK_INVALID; hit.prim = VMK_INVALID; hit.tri = VMK_INVALID; hit.bary = {0.f, 0.f};
     if (S.n_tris == 0) return false;
@@ -372,7 +409,7 @@ VD bool traverse_wave(const DScene &S, const Ray &r, bool active, bool any_hit, 
     }
     wave_lds_fence();
     LdsRayIO io = {ws, n_act, 0};
-    traverse_core<LdsRayIO, COUNT, DEEP>(S, io, ws, cnt, nullptr);
+    traverse_core<LdsRayIO, COUNT, DEEP, ANYHIT>(S, io, ws, cnt, nullptr);
     wave_lds_fence();
     bool res = false;
     if (active) {

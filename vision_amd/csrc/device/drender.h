@@ -87,7 +87,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
     const bool tail = ps.bounces >= max_depth; // the supplement pass (see above)
     Hit hit;
     if (active) cnt.closest++;
-    bool found = traverse_wave<COUNT, DEEP>(S, ps.ray, active, false, ws, hit, cnt);
+    bool found = traverse_wave<COUNT, DEEP, false>(S, ps.ray, active, ws, hit, cnt);
     if (dbg && active) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
     bool shade = false; // the lane reached a surface with a material: NEE + scattering follow
     Interaction it;
@@ -162,7 +162,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
         }
     }
     Hit sh;
-    bool occluded = traverse_wave<COUNT, DEEP>(S, shadow_ray, shade, true, ws, sh, cnt);
+    bool occluded = traverse_wave<COUNT, DEEP, true>(S, shadow_ray, shade, ws, sh, cnt); // (the occlusion-query instance of the loop)
     if (!shade) return pass_through ? kPathGoOn : kPathEnd;
     Spec tr_shadow = mks(1.f);
     if constexpr (MEDIA) tr_shadow = geometry_Tr(S, P, shadow_ray, P->process_mediums ? (dot(it.ng, shadow_ray.d) > 0.f ? med_out : med_in) : VMK_INVALID SWL_A);
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
         V2 p_film;
         Ray ray = generate_ray(P, px, py, sampler, &p_film);
         Hit hit;
-        bool found = traverse_wave<true, true>(S, ray, live, false, ws, hit, cnt); // (DEEP: serves every tree)
+        bool found = traverse_wave<true, true, false>(S, ray, live, ws, hit, cnt); // (DEEP: serves every tree)
         if (!live) continue;
         V3 normal = mk3(0.f), albedo = mk3(0.f), emission = mk3(0.f);
         float depth = 0.f;

@@ -258,7 +258,7 @@ __global__ void k_film_resolve(RenderRest A) {
 // ---------------------------------------------------------------------------------------------------------
 // traversal replay, tone map, unit tests
 // ---------------------------------------------------------------------------------------------------------
-template<bool DEEP>
+template<bool DEEP, bool ANYHIT>
 __global__ __launch_bounds__(kBlock) void k_trace(const DScene S, uint32_t n, const float *org, const float *dir, const float *tmax,
                                                   int any_hit, uint32_t *hit_out, unsigned long long *counters, uint32_t *queue, uint32_t chunk) {
     __shared__ WaveScratch s_ws[kBlock / 64];
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const DScene S, uint32_t n, co
     uint32_t n_rays = 0;
     if (S.n_tris == 0) { // nothing to hit
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { io.store((int) i, false, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); ++n_rays; }
-    } else traverse_core<GlobalRayIO, true, DEEP>(S, io, ws, cnt, &n_rays);
+    } else traverse_core<GlobalRayIO, true, DEEP, ANYHIT>(S, io, ws, cnt, &n_rays);
     if (any_hit) cnt.shadow += n_rays; else cnt.closest += n_rays;
     uint32_t c[4] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris};
     for (int k = 0; k < 4; ++k) { uint32_t s = wave_sum(c[k]); if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + k, (unsigned long long) s); }
@@ -888,6 +888,7 @@ int vmk_build_accel(vmk_ctx *ctx) {
     cleanup();
 #undef BUILD_TRY
     if (h_nodes > n_int) { ctx->error = "vmk_build_accel: BVH4 node count exceeds the allocation"; return VMK_ERR_STATE; }
+    if ((uint64_t) n * sizeof(vmk_tri_pos) > 0xffffffffull) { ctx->error = "vmk_build_accel: triangle array exceeds the 4 GiB the traversal's 32-bit offsets address"; return VMK_ERR_UNSUPPORTED; }
     if ((uint64_t) h_nodes * sizeof(BvhNode) > 0xffffffffull) { ctx->error = "vmk_build_accel: node array exceeds the 4 GiB the traversal's 32-bit node offsets address"; return VMK_ERR_UNSUPPORTED; }
     if (h_scalars[0] > kQuadStack + kStackOverflow) { ctx->error = "vmk_build_accel: worst-case traversal stack need " + std::to_string(h_scalars[0]) + " exceeds the per-ray stack (" + std::to_string(kQuadStack) + " entries in LDS + " + std::to_string(kStackOverflow) + " in HBM)"; return VMK_ERR_UNSUPPORTED; }
     ctx->stack_overflow.release();
@@ -1243,8 +1244,10 @@ int vmk_trace_rays(vmk_ctx *ctx, uint32_t n, const float *org_xyz, const float *
     (void) hipEventRecord(ctx->ev0, ctx->stream);
     for (uint32_t r = 0; r < repeats; ++r) {
         (void) hipMemsetAsync(ctx->queue.p, 0, sizeof(uint32_t), ctx->stream);
-        if (ctx->stack_overflow.p) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, static_cast<const DScene &>(ctx->h_scene), n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
-        else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, static_cast<const DScene &>(ctx->h_scene), n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
+        {
+            auto kern = ctx->stack_overflow.p ? (any_hit ? k_trace<true, true> : k_trace<true, false>) : (any_hit ? k_trace<false, true> : k_trace<false, false>);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, ctx->stream, static_cast<const DScene &>(ctx->h_scene), n, o.p, d.p, t.p, any_hit, h.p, ctx->counters.p, ctx->queue.p, chunk);
+        }
     }
     (void) hipEventRecord(ctx->ev1, ctx->stream);
     e = hipMemcpyAsync(hit_out, h.p, (size_t) n * 16, hipMemcpyDeviceToHost, ctx->stream);
