@@ -233,7 +233,53 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
     uint32_t *const ovf = (DEEP && S.stack_overflow) ? S.stack_overflow + ((size_t) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kStackOverflow) * 64u + lane : nullptr;
 #define VMK_POP() do { if (sp > 0) { --sp; if constexpr (DEEP) cur = sp < kQuadStack ? (int32_t) ws->stack[sp][quad] : (int32_t) ovf[(size_t) (sp - kQuadStack) * 64u]; else cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
 
+    // Loop shape: the OUTER loop is one hand-back / refill round (it also starts the traversal: every quad is idle and owns nothing); the
+    // INNER do-while alternates node and leaf phases and has a single back-edge.  With the refill inside the same loop as the phases (two
+    // `continue`s and a fall-through back-edge) the register allocator copied the whole per-ray state — some 25 registers — at the merge
+    // on every round whether or not a quad took a ray; keeping the state's redefinition out of the inner loop confines that to the
+    // refill rounds.
     for (;;) {
+        // ================= hand back hits, take new rays =================
+        {
+            const bool idle = cur == kTravDone && pend == kTravDone;
+            if constexpr (ANYHIT) { if (idle && owner >= 0) { if (q == 0) io.store(owner, found, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); owner = -1; } }
+            else if (idle && owner >= 0) {
+                // ---- retire: the lane that holds the quad's best candidate (min t, then inst, then prim) returns it ----
+                float m = found ? bt : __builtin_inff();
+                m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
+                m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
+                const bool c1 = found && bt == m;
+                uint32_t ki = c1 ? binst : 0xffffffffu;
+                ki = min(ki, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) ki));
+                ki = min(ki, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) ki));
+                const bool c2 = c1 && binst == ki;
+                uint32_t kp = c2 ? bprim : 0xffffffffu;
+                kp = min(kp, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) kp));
+                kp = min(kp, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) kp));
+                const bool none = !(m < __builtin_inff());
+                if (c2 && bprim == kp) io.store(owner, true, binst, bprim, btri, bu, bv);
+                else if (none && q == 0) io.store(owner, false, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f);
+                owner = -1;
+            }
+            // ---- refill ----
+            const unsigned long long idle_mask = __ballot(idle && q == 0);
+            const uint32_t base = io.more() ? io.claim((uint32_t) __popcll(idle_mask)) : 0xffffffffu;
+            if (idle && base != 0xffffffffu) {
+                uint32_t idx = base + (uint32_t) __popcll(idle_mask & ((1ull << (lane & ~3u)) - 1ull));
+                V3 d;
+                if (io.load(idx, owner, o, d, t_max, anyh)) {
+                    tray = tri_ray_setup(d);
+                    // v_rcp_f32 (1 ulp) is enough here: inv only feeds the padded, conservative slab test
+                    inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
+                    best_t = t_max; cur = S.root; sp = 0;
+                    found = false; bt = t_max; binst = VMK_INVALID; bprim = VMK_INVALID; btri = VMK_INVALID; bu = 0.f; bv = 0.f;
+                    nr += q == 0 ? 1u : 0u;
+                }
+            }
+            if (!__any(owner >= 0)) break; // nothing in flight and nothing left to take
+        }
+        bool again;
+        do {
         // ================= node phase =================
         for (bool first = true;; first = false) {
             const bool at_node = (uint32_t) cur < (uint32_t) kEmptyRef;
@@ -342,47 +388,13 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
             }
         }
         if (cur < 0) { pend = cur; VMK_POP(); } // a second leaf was waiting: park it for the next leaf phase
-        // ================= hand back hits, take new rays =================
+        // ---- back to the refill round once enough quads are idle (or nothing else is left) ----
         const bool idle = cur == kTravDone && pend == kTravDone;
         const bool want = idle && (owner >= 0 || io.more());
         const unsigned long long want_mask = __ballot(want);
         const bool any_busy = __any(!idle);
-        if (want_mask == 0) { if (!any_busy) break; continue; }
-        if (any_busy && __popcll(want_mask) < 4 * VMK_REFILL_QUADS_MIN) continue;
-        if constexpr (ANYHIT) { if (idle && owner >= 0) { if (q == 0) io.store(owner, found, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); owner = -1; } }
-        else if (idle && owner >= 0) {
-            // ---- retire: the lane that holds the quad's best candidate (min t, then inst, then prim) returns it ----
-            float m = found ? bt : __builtin_inff();
-            m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
-            m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
-            const bool c1 = found && bt == m;
-            uint32_t ki = c1 ? binst : 0xffffffffu;
-            ki = min(ki, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) ki));
-            ki = min(ki, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) ki));
-            const bool c2 = c1 && binst == ki;
-            uint32_t kp = c2 ? bprim : 0xffffffffu;
-            kp = min(kp, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) kp));
-            kp = min(kp, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) kp));
-            const bool none = !(m < __builtin_inff());
-            if (c2 && bprim == kp) io.store(owner, true, binst, bprim, btri, bu, bv);
-            else if (none && q == 0) io.store(owner, false, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f);
-            owner = -1;
-        }
-        // ---- refill ----
-        const unsigned long long idle_mask = __ballot(idle && q == 0);
-        const uint32_t base = io.more() ? io.claim((uint32_t) __popcll(idle_mask)) : 0xffffffffu;
-        if (idle && base != 0xffffffffu) {
-            uint32_t idx = base + (uint32_t) __popcll(idle_mask & ((1ull << (lane & ~3u)) - 1ull));
-            V3 d;
-            if (io.load(idx, owner, o, d, t_max, anyh)) {
-                tray = tri_ray_setup(d);
-                // v_rcp_f32 (1 ulp) is enough here: inv only feeds the padded, conservative slab test
-                inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
-                best_t = t_max; cur = S.root; sp = 0;
-                found = false; bt = t_max; binst = VMK_INVALID; bprim = VMK_INVALID; btri = VMK_INVALID; bu = 0.f; bv = 0.f;
-                nr += q == 0 ? 1u : 0u;
-            }
-        }
+        again = any_busy && (want_mask == 0 || __popcll(want_mask) < 4 * VMK_REFILL_QUADS_MIN);
+        } while (again);
     }
 #undef VMK_POP
     cnt.nodes += nn; cnt.tris += nt;
