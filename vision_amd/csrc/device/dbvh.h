@@ -124,7 +124,7 @@ VD bool hit_box(f2v bx, f2v by, f2v bz, V3 o, V3 inv, float t_far, float *t_near
 #define VMK_CULL_LO 0.9999f
 #define VMK_CULL_HI 1.0001f
 #endif
-    return tn * VMK_CULL_LO <= tf * VMK_CULL_HI;
+    return tn <= tf * (VMK_CULL_HI / VMK_CULL_LO); // (one multiply: the two factors folded)
 }
 
 VD void wave_lds_fence() { // LDS written by other lanes of this wave is visible after this point
@@ -222,6 +222,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
     int owner = -1;
     V3 o = mk3(0.f), inv = mk3(0.f);
     TriRay tray = {mk3(0.f), false, false}; // the watertight triangle test's view of the ray direction (kept instead of d)
+    uint32_t oct4 = 0;                      // 4 x the sign octant of d (bit 0: d.x < 0, bit 1: d.y < 0, bit 2: d.z < 0): selects the child-order nibble
     float t_max = 0.f, best_t = 0.f; // best_t: quad-wide culling bound
     bool anyh = false;
     // lane-local best candidate (merged across the quad when the ray retires)
@@ -269,6 +270,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 V3 d;
                 if (io.load(idx, owner, o, d, t_max, anyh)) {
                     tray = tri_ray_setup(d);
+                    oct4 = ((f2u(d.x) >> 31) | ((f2u(d.y) >> 31) << 1) | ((f2u(d.z) >> 31) << 2)) * 4u;
                     // v_rcp_f32 (1 ulp) is enough here: inv only feeds the padded, conservative slab test
                     inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
                     best_t = t_max; cur = S.root; sp = 0;
@@ -312,15 +314,15 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                     cand = max(cand, quad_perm_i<kQuadXor1>(cand));
                     cand = max(cand, quad_perm_i<kQuadXor2>(cand));
                 } else {
-                // order key: entry distance (non-negative float bits order like integers) with the lane id in the two low
-                // mantissa bits, so keys are distinct and three unsigned compares rank the children; misses sort last.  The
-                // visiting order only steers culling, it never changes which hit is returned.
-                key = h ? ((f2u(tn) & ~3u) | q) : 0xffffffffu;
-                k1 = (uint32_t) quad_perm_i<kQuadXor1>((int32_t) key); k2 = (uint32_t) quad_perm_i<kQuadXor2>((int32_t) key); k3 = (uint32_t) quad_perm_i<kQuadXor3>((int32_t) key);
-                rank = (k1 < key ? 1 : 0) + (k2 < key ? 1 : 0) + (k3 < key ? 1 : 0);
-                n = h ? 1 : 0;
-                n += quad_perm_i<kQuadXor1>(n);
-                n += quad_perm_i<kQuadXor2>(n);
+                // Order of the children: NOT sorted by entry distance at run time.  The node carries, per child and per sign octant of the
+                // ray direction, the set of siblings that precede the child front to back (k_bvh4_level); intersected with the quad's hit
+                // mask (one ballot) that is the child's rank among the children that were hit.  The order only steers culling, it never
+                // changes which hit is returned.  (Exact distance ranking — a key per lane, three DPP reads and compares — cost twice
+                // the instructions in a loop that is bound by VALU issue.)
+                const uint32_t hits = (uint32_t) (__ballot(h) >> (lane & ~3u)) & 0xfu;
+                const uint32_t before = (f2u(b.w) >> oct4) & 0xfu;
+                n = __popc(hits);
+                rank = __popc(hits & before);
                 cand = (h && rank == 0) ? ref : (int32_t) 0x80000000;
                 cand = max(cand, quad_perm_i<kQuadXor1>(cand));
                 cand = max(cand, quad_perm_i<kQuadXor2>(cand));
@@ -330,7 +332,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                     if (slot < kQuadStack) ws->stack[slot][quad] = (uint32_t) ref;
                 }
                 if constexpr (DEEP) if (sp + n - 1 > kQuadStack && ovf) { // cold: some of the far children land beyond the LDS stack (deep trees only)
-                    if constexpr (ANYHIT) { // the same placement expressed as keys: rank 0 for the child descended into, then lane order
+                    { // the same placement expressed as keys (rank, then lane)
                         key = h ? (uint32_t) rank * 4u + q : 0xffffffffu;
                         k1 = (uint32_t) quad_perm_i<kQuadXor1>((int32_t) key); k2 = (uint32_t) quad_perm_i<kQuadXor2>((int32_t) key); k3 = (uint32_t) quad_perm_i<kQuadXor3>((int32_t) key);
                     }

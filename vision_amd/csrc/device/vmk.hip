@@ -228,6 +228,28 @@ __global__ void k_bvh4_level(const Bvh4Work *in, int n_in, Bvh4Work *out_q, int 
             out_q[atomicAdd(out_count, 1)] = {slot[k], o, first[k], w.acc + ns - 1};
         }
     }
+    // Front-to-back order without a sort at run time: child q's spare word holds, for each of the 8 sign octants of a ray direction, the
+    // 4-bit set of its siblings that come BEFORE it when the children are ordered by the projection of their box centres on the octant's
+    // diagonal (ties by slot).  The traversal reads its octant's nibble and intersects it with the quad's hit mask (dbvh.h).
+    {
+        float cx[4], cy[4], cz[4];
+        for (int k = 0; k < 4; ++k) { const BvhChild &ch = nd.child[k]; cx[k] = ch.x[0] + ch.x[1]; cy[k] = ch.y[0] + ch.y[1]; cz[k] = ch.z[0] + ch.z[1]; }
+        for (int k = 0; k < ns; ++k) {
+            uint32_t word = 0;
+            for (int oct = 0; oct < 8; ++oct) {
+                const float sx = (oct & 1) ? -1.f : 1.f, sy = (oct & 2) ? -1.f : 1.f, sz = (oct & 4) ? -1.f : 1.f;
+                const float mine = sx * cx[k] + sy * cy[k] + sz * cz[k];
+                uint32_t before = 0;
+                for (int j = 0; j < ns; ++j) {
+                    if (j == k) continue;
+                    const float other = sx * cx[j] + sy * cy[j] + sz * cz[j];
+                    if (other < mine || (other == mine && j < k)) before |= 1u << j;
+                }
+                word |= before << (4 * oct);
+            }
+            nd.child[k].pad = word;
+        }
+    }
     nodes[w.out] = nd;
     if (leaves) atomicAdd(n_leaves, leaves);
     atomicMax(max_need, w.acc + ns - 1);
