@@ -231,8 +231,14 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
     bool found = false;
     uint32_t nn = 0, nt = 0, nr = 0;
     // this wave's slice of the HBM stack overflow (null unless the tree needs it)
-    uint32_t *const ovf = (DEEP && S.stack_overflow) ? S.stack_overflow + ((size_t) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kStackOverflow) * 64u + lane : nullptr;
-#define VMK_POP() do { if (sp > 0) { --sp; if constexpr (DEEP) cur = sp < kQuadStack ? (int32_t) ws->stack[sp][quad] : (int32_t) ovf[(size_t) (sp - kQuadStack) * 64u]; else cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
+    // Deep trees: the entries beyond the LDS stack live in HBM.  The address of this lane's slice is NOT kept in registers — it is rebuilt
+    // from scalars inside the (cold) branches that touch it, so a tree that fits the LDS stack by a wide margin most of the time pays one
+    // compare per pop and per push for the variant.
+    const bool has_ovf = DEEP && S.stack_overflow != nullptr;
+    auto ovf_slot = [&](int entry) -> uint32_t * {
+        return S.stack_overflow + (((size_t) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kStackOverflow + (size_t) (entry - kQuadStack)) * 64u + lane);
+    };
+#define VMK_POP() do { if (sp > 0) { --sp; if (DEEP && __builtin_expect(sp >= kQuadStack, 0)) cur = (int32_t) *ovf_slot(sp); else cur = (int32_t) ws->stack[sp][quad]; } else cur = kTravDone; } while (0)
 
     // Loop shape: the OUTER loop is one hand-back / refill round (it also starts the traversal: every quad is idle and owns nothing); the
     // INNER do-while alternates node and leaf phases and has a single back-edge.  With the refill inside the same loop as the phases (two
@@ -331,7 +337,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                     int slot = sp + (n - 1 - rank);
                     if (slot < kQuadStack) ws->stack[slot][quad] = (uint32_t) ref;
                 }
-                if constexpr (DEEP) if (sp + n - 1 > kQuadStack && ovf) { // cold: some of the far children land beyond the LDS stack (deep trees only)
+                if constexpr (DEEP) if (__builtin_expect(sp + n - 1 > kQuadStack, 0) && has_ovf) { // cold: some of the far children land beyond the LDS stack (deep trees only)
                     { // the same placement expressed as keys (rank, then lane)
                         key = h ? (uint32_t) rank * 4u + q : 0xffffffffu;
                         k1 = (uint32_t) quad_perm_i<kQuadXor1>((int32_t) key); k2 = (uint32_t) quad_perm_i<kQuadXor2>((int32_t) key); k3 = (uint32_t) quad_perm_i<kQuadXor3>((int32_t) key);
@@ -346,7 +352,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
 #pragma unroll
                         for (int i = 0; i < 4; ++i) rank_j += kk[i] < kk[j] ? 1 : 0;
                         const int slot_j = sp + (n - 1 - rank_j);
-                        if (rank_j > 0 && slot_j >= kQuadStack && slot_j < kQuadStack + kStackOverflow) ovf[(size_t) (slot_j - kQuadStack) * 64u] = (uint32_t) rr[j];
+                        if (rank_j > 0 && slot_j >= kQuadStack && slot_j < kQuadStack + kStackOverflow) *ovf_slot(slot_j) = (uint32_t) rr[j];
                     }
                 }
                 // The pops below read entries that OTHER lanes of the quad have just written.  The hardware keeps the LDS
@@ -355,7 +361,7 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 // divergent `if` above nor sink loads across (no instruction is emitted for it).  Without it the order of
                 // the two was a property of the block layout the optimiser happened to pick ("UB").
                 wave_lds_fence();
-                if (n > 0) { cur = cand; sp = min(sp + n - 1, (DEEP && ovf) ? kQuadStack + kStackOverflow : kQuadStack); }
+                if (n > 0) { cur = cand; sp = min(sp + n - 1, has_ovf ? kQuadStack + kStackOverflow : kQuadStack); }
                 else VMK_POP();
                 if (cur < 0 && pend == kTravDone) { pend = cur; VMK_POP(); } // park the leaf, keep descending
             }

@@ -531,13 +531,16 @@ __global__ __launch_bounds__(kBlock) void k_aov(AovArgs A) {
 }
 
 
-// the twelve ahead-of-time variants: <FULL, MEDIA> x {tallying, not tallying} for trees that fit the LDS stack, and the tallying
-// <FULL, MEDIA> instances with the HBM stack overflow for deep trees
+// the sixteen ahead-of-time variants: <FULL, MEDIA> x {tallying, not tallying} x {trees that fit the LDS stack, deep trees with the HBM
+// stack overflow}
 typedef void (*RenderKernel)(RenderArgs);
+template<bool COUNT, bool DEEP>
+inline RenderKernel select_render_kernel_cd(bool full, bool media) {
+    return full ? (media ? k_render<true, true, COUNT, DEEP> : k_render<true, false, COUNT, DEEP>) : (media ? k_render<false, true, COUNT, DEEP> : k_render<false, false, COUNT, DEEP>);
+}
 inline RenderKernel select_render_kernel(bool full, bool media, bool count, bool deep) {
-    if (deep) return full ? (media ? k_render<true, true, true, true> : k_render<true, false, true, true>) : (media ? k_render<false, true, true, true> : k_render<false, false, true, true>);
-    if (count) return full ? (media ? k_render<true, true, true, false> : k_render<true, false, true, false>) : (media ? k_render<false, true, true, false> : k_render<false, false, true, false>);
-    return full ? (media ? k_render<true, true, false, false> : k_render<true, false, false, false>) : (media ? k_render<false, true, false, false> : k_render<false, false, false, false>);
+    if (deep) return count ? select_render_kernel_cd<true, true>(full, media) : select_render_kernel_cd<false, true>(full, media);
+    return count ? select_render_kernel_cd<true, false>(full, media) : select_render_kernel_cd<false, false>(full, media);
 }
 
 }// namespace vmkd

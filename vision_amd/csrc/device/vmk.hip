@@ -1042,6 +1042,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         const uint64_t n_items = (uint64_t) A.frame_count * n_slots;
         A.n_items = (uint32_t) n_items;
         uint32_t grid = (uint32_t) std::min<uint64_t>((n_items + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * (uint64_t) per_cu);
+        if (deep) grid = std::min<uint32_t>(grid, kOverflowWaves / (kBlock / 64)); // the HBM stack overflow is sized for kOverflowWaves waves of one grid
         // a wave claims `chunk` items per atomic: few enough claims to keep the counter cold, small enough to balance the tail
         uint64_t chunk = (n_items / ((uint64_t) grid * (kBlock / 64) * 8)) & ~63ull;
         A.chunk = (uint32_t) std::max<uint64_t>(64, std::min<uint64_t>(1024, chunk));
