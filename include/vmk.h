@@ -408,6 +408,11 @@ int vmk_test_eval(vmk_ctx *ctx, uint32_t kind, uint32_t n, const float *in, uint
  * scene selects and with the unit kernel (a separately compiled instance of the same path code) and compares the
  * radiance bit for bit.  Returns VMK_OK when they agree; the user's framebuffer and counters are left untouched. */
 int vmk_self_check(vmk_ctx *ctx, uint32_t max_pixels, uint32_t *n_checked, uint32_t *n_mismatch);
+/* By default the first vmk_render_batch after vmk_build_accel / vmk_set_render_params runs vmk_self_check(ctx, 256, ...) itself and
+ * fails with its status if the two instances disagree (one 1-spp frame + 256 unit-kernel paths, once per scene): a host that never
+ * heard of the toolchain's miscompiles is guarded anyway.  enabled = 0 opts out (benchmarks that time the very
+ * first batch; hosts that call vmk_self_check themselves). */
+int vmk_set_auto_self_check(vmk_ctx *ctx, int enabled);
 
 #ifdef __cplusplus
 }

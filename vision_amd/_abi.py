@@ -117,7 +117,7 @@ VMK_SYMBOLS = ["vmk_create", "vmk_destroy", "vmk_last_error", "vmk_abi_version",
                "vmk_build_accel", "vmk_set_render_params", "vmk_set_framebuffer", "vmk_reset_accum",
                "vmk_render_batch", "vmk_synchronize", "vmk_download_accum", "vmk_tonemap", "vmk_get_counters",
                "vmk_reset_counters", "vmk_set_traversal_counters", "vmk_stream", "vmk_accel_info_get", "vmk_trace_rays", "vmk_test_eval",
-               "vmk_precompute_albedo", "vmk_render_aov", "vmk_self_check", "vmk_tile_skew", "vmk_comm_unique_id", "vmk_comm_init",
+               "vmk_precompute_albedo", "vmk_render_aov", "vmk_self_check", "vmk_set_auto_self_check", "vmk_tile_skew", "vmk_comm_unique_id", "vmk_comm_init",
                "vmk_comm_adopt", "vmk_enable_kernel_timing", "vmk_collect_kernel_ms", "vmk_allreduce_framebuffer", "vmk_allgather_framebuffer", "vmk_comm_synchronize"]
 HOST_SYMBOLS = ["vmk_host_register_image", "vmk_host_clear_images", "vmk_host_list_images", "vmk_host_load_scene",
                 "vmk_host_free_scene", "vmk_host_scene_tables", "vmk_host_render_params", "vmk_host_output_spp",

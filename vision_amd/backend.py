@@ -201,6 +201,11 @@ class Backend:
         self._check(self._L.vmk_test_eval(self._h, kind, inp.shape[0], _ptr(inp), inp.shape[1], _ptr(out), out_stride))
         return out
 
+    def set_auto_self_check(self, enabled=True):
+        """vmk_set_auto_self_check: the self check the first vmk_render_batch after a build / parameter change runs by itself."""
+        self._L.vmk_set_auto_self_check.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._L.vmk_set_auto_self_check(self._h, int(bool(enabled))))
+
     def self_check(self, max_pixels=0):
         """vmk_self_check: megakernel variant vs unit kernel on frame 0 of a pixel subset; raises BackendError on a mismatch."""
         n, bad = C.c_uint32(0), C.c_uint32(0)

@@ -519,6 +519,7 @@ struct vmk_ctx {
     bool scene_ready{false}, accel_ready{false}, params_ready{false};
     bool full_materials{true}; // scene has mix / principled_bsdf -> lobe-set variant of the megakernel
     bool count_traversal{true}; // vmk_set_traversal_counters: launch the megakernel instance that tallies node fetches / triangle tests
+    bool auto_self_check{true}, self_checked{false}, in_self_check{false}; // vmk_set_auto_self_check: the guard a host gets without asking for it
     bool hero{false};          // vmk_scene::spectrum == VMK_SPECTRUM_HERO -> the vmk_hero.hip instance of the megakernel
     bool hero4{false};         // ... with spectrum_dimension == 4 -> the vmk_hero4.hip instance
     DevBuf<float> rgb2spec, spd;
@@ -925,6 +926,7 @@ int vmk_build_accel(vmk_ctx *ctx) {
     ctx->scene_ready = false; // host copies consumed; a new upload is needed before rebuilding
     ctx->accel = {h_nodes, h_leaves, (uint32_t) sizeof(BvhNode), (uint32_t) sizeof(vmk_tri_pos), ms, (uint32_t) h_scalars[0], (uint32_t) kQuadStack};
     ctx->accel_ready = true;
+    ctx->self_checked = false;
     return VMK_OK;
 }
 
@@ -957,6 +959,7 @@ int vmk_set_render_params(vmk_ctx *ctx, const vmk_render_params *p) {
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->params_ready = true;
+    ctx->self_checked = false; // (the parameters select the kernel variant)
     return VMK_OK;
 }
 
@@ -983,6 +986,16 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     if (ctx->params.light_sampler == 1 && !ctx->has_light_alias) { ctx->error = "vmk_render_batch: the power light sampler needs vmk_scene::light_alias_offset"; return VMK_ERR_ARG; }
     if (kernel_ms) *kernel_ms = 0.f;
     if (frame_count == 0) return VMK_OK;
+    if (ctx->auto_self_check && !ctx->self_checked && !ctx->in_self_check) {
+        // the first batch after a build / a parameter change: the megakernel variant this scene selects against its separately compiled twin
+        // on 256 pixels of frame 0 (vmk_self_check) — the guard against the toolchain's miscompiles that a Vision-side user gets by default
+        ctx->in_self_check = true;
+        uint32_t n = 0, bad = 0;
+        const int rc = vmk_self_check(ctx, 256, &n, &bad);
+        ctx->in_self_check = false;
+        if (rc != VMK_OK) return rc;
+        ctx->self_checked = true;
+    }
     RenderArgs A{};
     A.scene = ctx->h_scene; A.params = ctx->d_params.p; A.accum = ctx->fb; A.queue = ctx->queue.p; A.counters = ctx->counters.p;
     uint32_t ts = kDefaultTile, rank = 0, world = 1;
@@ -1234,6 +1247,12 @@ int vmk_get_counters(vmk_ctx *ctx, vmk_counters *out) {
     out->closest_rays = h[0]; out->shadow_rays = h[1]; out->nodes_visited = h[2]; out->tris_tested = h[3]; out->paths = h[4]; out->surface_hits = h[5]; out->tex_fetches = h[6];
     return VMK_OK;
 }
+int vmk_set_auto_self_check(vmk_ctx *ctx, int enabled) {
+    if (!ctx) return VMK_ERR_ARG;
+    ctx->auto_self_check = enabled != 0;
+    return VMK_OK;
+}
+
 int vmk_set_traversal_counters(vmk_ctx *ctx, int enabled) {
     if (!ctx) return VMK_ERR_ARG;
     ctx->count_traversal = enabled != 0;
@@ -1457,6 +1476,7 @@ int vmk_self_check(vmk_ctx *ctx, uint32_t max_pixels, uint32_t *n_checked, uint3
         }
     if (n_checked) *n_checked = (uint32_t) idx.size();
     if (n_mismatch) *n_mismatch = bad;
+    if (!bad) ctx->self_checked = true;
     if (bad) { ctx->error = "vmk_self_check: " + std::to_string(bad) + " of " + std::to_string(idx.size()) + " pixels differ between the megakernel and the unit kernel"; return VMK_ERR_STATE; }
     return VMK_OK;
 }
