@@ -46,6 +46,55 @@ def algorithmic_bytes(c, pixels, launches, env_lit, texel_bytes):
     return trav + hit + tex + nee + film, trav
 
 
+def cpu_budget():
+    """Hardware threads this process may actually run on: the scheduler affinity, cut down to the cgroup's CPU quota when there is one
+    (a GPU box hands a job 16 CPUs of a 256-thread host; 256 oracle threads on 16 CPUs time-slice and the measured rate falls)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("VMK_CPU_THREADS"):
+        n = max(1, min(n, int(os.environ["VMK_CPU_THREADS"])))
+    return n
+
+
+def quick_config(name, device, tile):
+    """One BASELINE configuration measured briefly on one GPU, after the headline's timed region: a warm-up step and a timed step of the
+    non-tallying megakernel instance, then the same frames through the tallying instance for the algorithmic bytes."""
+    from vision_amd.pipeline import Pipeline
+    from vision_amd import _abi
+    scene_rel, w, h, host_kw, workload = CONFIGS[name]
+    spp = 64 if w * h > 4000000 else 256
+    pipe = Pipeline(os.path.join(ROOT, scene_rel), device=device, width=w, height=h, **host_kw)
+    try:
+        pipe.prepare()
+        be = pipe.backend
+        be.set_traversal_counters(False)
+        pipe.render(frames=spp)               # warm-up (and the automatic self check of the first batch)
+        be.reset_counters()
+        ms = pipe.render(frames=spp)          # timed: HIP events around the launches of this batch
+        c = pipe.counters()
+        be.set_traversal_counters(True)
+        be.reset_counters()
+        be.render_batch(spp, spp)
+        be.synchronize()
+        sib = pipe.counters()
+        c = dict(c, nodes_visited=sib["nodes_visited"], tris_tested=sib["tris_tested"])
+        rays = c["closest_rays"] + c["shadow_rays"]
+        b_all, _ = algorithmic_bytes(c, w * h, 1, pipe.host_scene.scene.env_light != _abi.INVALID, 4)
+        gbs = b_all / (ms * 1e-3) / 1e9
+        return {"workload": workload, "value": rays / ms / 1e3, "unit": "Mrays/s", "ms_per_step": ms, "spp_per_step": spp,
+                "frac": gbs / HBM_PEAK_GBS, "achieved_GBs": gbs, "nodes_per_ray": c["nodes_visited"] / max(rays, 1), "rays_per_path": rays / max(c["paths"], 1)}
+    finally:
+        pipe.close()
+
+
 CONFIGS = {  # BASELINE.json configs -> (scene, width, height, host options, description)
     "c3": ("scenes/classroom/vision_scene.json", 1920, 1080, {}, "classroom 1920x1080, env-lit, box filter"),
     "c2": ("scenes/cbox/cbox_matte.json", 1024, 1024, {}, "cbox 1024x1024, matte-only BSDFs"),
@@ -72,6 +121,7 @@ def main():
     ap.add_argument("--no-replay", action="store_true", help="skip the traversal-only replay of the megakernel's own rays")
     ap.add_argument("--no-self-check", action="store_true", help="skip vmk_self_check (profiling runs: keeps every k_render dispatch a timed step)")
     ap.add_argument("--no-sibling", action="store_true", help="skip the counting sibling pass (roofline.achieved is then null)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of BASELINE configs c2 / c4 / c5 after the timed region (N = 1, config c3 only)")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal on one GPU: run the per-step C-ABI exchange with a 1-rank communicator")
     ap.add_argument("--save", default=None, help="write the final tone-mapped picture (rank 0)")
     a = ap.parse_args()
@@ -293,19 +343,24 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             from oracle import oracle_py
             osc = oracle_py.OracleScene(pipe.host_scene)
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except AttributeError:
-                cores = os.cpu_count() or 1
-            if os.environ.get("VMK_CPU_THREADS"):
-                cores = max(1, min(cores, int(os.environ["VMK_CPU_THREADS"])))
-            sub, nf = 4, 8  # every 4th 32x32 tile of the same image, frames 0..7 (about 10-20 s)
+            cores = cpu_budget()
+            sub, nf = 4, 8  # every 4th 32x32 tile of the same image, frames 0..7 (about 10-30 s; the oracle's work queue is tile-granular)
             t1 = time.perf_counter()
             _, cc = osc.render(params, 0, nf, tiles=_abi.Tiles(a.tile, 0, sub), threads=cores)
             dt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": (cc["closest_rays"] + cc["shadow_rays"]) / dt / 1e6, "unit": "Mrays/s", "cores": cores,
+            v = (cc["closest_rays"] + cc["shadow_rays"]) / dt / 1e6
+            out["cpu_baseline"] = {"value": v, "unit": "Mrays/s", "cores": cores, "per_core": v / cores,
                                    "kind": "port", "sample": f"same scene/resolution, every {sub}th {a.tile}x{a.tile} tile, frames 0-{nf - 1} "
-                                                             f"({cc['paths']} paths, {dt:.1f} s) on all {cores} host threads this process may use; build CPU restatement (not Vision/ocarina)"}
+                                                             f"({cc['paths']} paths, {dt:.1f} s) on the {cores} hardware threads this process may use (affinity and cgroup quota); build CPU restatement (not Vision/ocarina)"}
+        if world == 1 and a.config == "c3" and not a.no_other_configs and not a.scene:
+            # the other BASELINE configurations that fit one GPU, measured after the timed region (each a warm-up + one timed step)
+            pipe.close()
+            out["other_configs"] = {}
+            for name in ("c2", "c4", "c5"):
+                try:
+                    out["other_configs"][name] = quick_config(name, local_rank, a.tile)
+                except Exception as e:  # never lose the headline line to a side measurement
+                    out["other_configs"][name] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

@@ -1821,13 +1821,20 @@ int orc_render(void *h, const vmk_render_params *p, uint32_t frame_begin, uint32
                float *accum, uint32_t n_threads, vmk_counters *counters) {
     SceneView &sv = ((orc_scene_handle *) h)->sv;
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
-    std::atomic<uint32_t> next_row{0};
+    // work queue: one 32 x 32 pixel block per claim (the tile of vmk_tiles when tiles are given), so that a sharded or sub-sampled job —
+    // bench.py's cpu_baseline renders every 4th tile — still hands every thread many items (whole rows left ~4 items per thread on a
+    // 256-thread host and the measured rate FELL with the thread count)
+    const uint32_t bs = (tiles && tiles->tile_size) ? tiles->tile_size : 32u;
+    const uint32_t bx = (p->width + bs - 1) / bs, by = (p->height + bs - 1) / bs;
+    std::atomic<uint32_t> next_block{0};
     auto worker = [&]() {
         for (;;) {
-            uint32_t y = next_row.fetch_add(1);
-            if (y >= p->height) break;
-            for (uint32_t x = 0; x < p->width; ++x) {
-                if (!tile_owned(tiles, x, y, p->width, p->height)) continue;
+            uint32_t b = next_block.fetch_add(1);
+            if (b >= bx * by) break;
+            const uint32_t x0 = (b % bx) * bs, y0 = (b / bx) * bs;
+            if (!tile_owned(tiles, x0, y0, p->width, p->height)) continue;
+            for (uint32_t y = y0; y < std::min(y0 + bs, p->height); ++y)
+            for (uint32_t x = x0; x < std::min(x0 + bs, p->width); ++x) {
                 float *px = accum + ((size_t) y * p->width + x) * 4;
                 float4 acc = {px[0], px[1], px[2], px[3]};
                 for (uint32_t f = frame_begin; f < frame_begin + frame_count; ++f) {

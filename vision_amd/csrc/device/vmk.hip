@@ -1040,7 +1040,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (!kernel_ms && ctx->timing) { // asynchronous timing: events only, read back by vmk_collect_kernel_ms
+    if (!kernel_ms && ctx->timing && !ctx->in_self_check) { // asynchronous timing: events only, read back by vmk_collect_kernel_ms (the self check's own frame is not a user batch)
         if (ctx->time_used == ctx->time_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
