@@ -1039,6 +1039,7 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
     if (ctx->hero) HIP_TRY((ctx->hero4 ? vmk_hero4_occupancy : vmk_hero_occupancy)(ctx->full_materials, media, count, deep, &per_cu));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     if (per_cu < 1) per_cu = 1;
+    if (const char *cap = getenv("VMK_MAX_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(cap))); // occupancy experiments (tools/gpu_occupancy.sh)
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (!kernel_ms && ctx->timing && !ctx->in_self_check) { // asynchronous timing: events only, read back by vmk_collect_kernel_ms (the self check's own frame is not a user batch)
         if (ctx->time_used == ctx->time_pool.size()) {
