@@ -518,6 +518,7 @@ struct vmk_ctx {
     // scene
     bool scene_ready{false}, accel_ready{false}, params_ready{false};
     bool full_materials{true}; // scene has mix / principled_bsdf -> lobe-set variant of the megakernel
+    int comm_world{0}, comm_rank{0}; // of the attached communicator (vmk_comm_init / vmk_comm_adopt)
     bool count_traversal{true}; // vmk_set_traversal_counters: launch the megakernel instance that tallies node fetches / triangle tests
     bool auto_self_check{true}, self_checked{false}, in_self_check{false}; // vmk_set_auto_self_check: the guard a host gets without asking for it
     bool hero{false};          // vmk_scene::spectrum == VMK_SPECTRUM_HERO -> the vmk_hero.hip instance of the megakernel
@@ -578,6 +579,8 @@ struct RcclApi {
     void *lib{nullptr};
     decltype(&ncclGetUniqueId) GetUniqueId{nullptr};
     decltype(&ncclCommInitRank) CommInitRank{nullptr};
+    decltype(&ncclCommCount) CommCount{nullptr};
+    decltype(&ncclCommUserRank) CommUserRank{nullptr};
     decltype(&ncclCommDestroy) CommDestroy{nullptr};
     decltype(&ncclAllReduce) AllReduce{nullptr};
     decltype(&ncclAllGather) AllGather{nullptr};
@@ -594,7 +597,7 @@ static bool rccl_load(std::string &err) {
     if (!h) { err = std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : "?"); return false; }
     RcclApi a; a.lib = h;
 #define VMK_SYM(field, name) a.field = (decltype(a.field)) dlsym(h, name); if (!a.field) { err = std::string("RCCL symbol missing: ") + name; dlclose(h); return false; }
-    VMK_SYM(GetUniqueId, "ncclGetUniqueId") VMK_SYM(CommInitRank, "ncclCommInitRank") VMK_SYM(CommDestroy, "ncclCommDestroy")
+    VMK_SYM(GetUniqueId, "ncclGetUniqueId") VMK_SYM(CommInitRank, "ncclCommInitRank") VMK_SYM(CommCount, "ncclCommCount") VMK_SYM(CommUserRank, "ncclCommUserRank") VMK_SYM(CommDestroy, "ncclCommDestroy")
     VMK_SYM(AllReduce, "ncclAllReduce") VMK_SYM(AllGather, "ncclAllGather") VMK_SYM(GetErrorString, "ncclGetErrorString")
 #undef VMK_SYM
     g_rccl = a;
@@ -1056,7 +1059,11 @@ int vmk_render_batch(vmk_ctx *ctx, uint32_t frame_begin, uint32_t frame_count, c
         const uint64_t n_items = (uint64_t) A.frame_count * n_slots;
         A.n_items = (uint32_t) n_items;
         uint32_t grid = (uint32_t) std::min<uint64_t>((n_items + kBlock - 1) / kBlock, (uint64_t) ctx->n_cus * (uint64_t) per_cu);
-        if (deep) grid = std::min<uint32_t>(grid, kOverflowWaves / (kBlock / 64)); // the HBM stack overflow is sized for kOverflowWaves waves of one grid
+        if (deep) grid = std::min<uint32_t>(grid, kOverflowWaves / (kBlock / 64));
+        // With a communicator attached the persistent grid leaves a few block slots free: the exchange of the previous batch runs as RCCL
+        // kernels on the second stream, and a grid that fills every wave slot would hold them back until its own blocks start to retire.
+        // 1/64 of the grid (24 of 1536 blocks) costs the megakernel that fraction and lets the collective run under it.
+        if (ctx->comm && ctx->comm_world > 1 && grid > 64) grid -= std::max<uint32_t>(1u, grid / 64u); // the HBM stack overflow is sized for kOverflowWaves waves of one grid
         // a wave claims `chunk` items per atomic: few enough claims to keep the counter cold, small enough to balance the tail
         uint64_t chunk = (n_items / ((uint64_t) grid * (kBlock / 64) * 8)) & ~63ull;
         A.chunk = (uint32_t) std::max<uint64_t>(64, std::min<uint64_t>(1024, chunk));
@@ -1139,7 +1146,7 @@ int vmk_comm_init(vmk_ctx *ctx, const void *unique_id, int rank, int world) {
     ncclComm_t comm = nullptr;
     ncclResult_t r = g_rccl.CommInitRank(&comm, world, id, rank);
     if (r != ncclSuccess) { ctx->error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); return VMK_ERR_HIP; }
-    ctx->comm = comm; ctx->comm_owned = true;
+    ctx->comm = comm; ctx->comm_owned = true; ctx->comm_world = world; ctx->comm_rank = rank;
     return VMK_OK;
 }
 int vmk_comm_adopt(vmk_ctx *ctx, void *nccl_comm) {
@@ -1149,7 +1156,11 @@ int vmk_comm_adopt(vmk_ctx *ctx, void *nccl_comm) {
     vmk_comm_release(ctx);
     int rc = comm_prepare(ctx);
     if (rc != VMK_OK) return rc;
-    ctx->comm = nccl_comm; ctx->comm_owned = false;
+    int cw = 0, cr = 0; // the communicator's own idea of its size and this process's place in it (checked against every vmk_tiles handed in)
+    ncclResult_t r = g_rccl.CommCount((ncclComm_t) nccl_comm, &cw);
+    if (r == ncclSuccess) r = g_rccl.CommUserRank((ncclComm_t) nccl_comm, &cr);
+    if (r != ncclSuccess) { ctx->error = std::string("vmk_comm_adopt: ") + g_rccl.GetErrorString(r); return VMK_ERR_HIP; }
+    ctx->comm = nccl_comm; ctx->comm_owned = false; ctx->comm_world = cw; ctx->comm_rank = cr;
     return VMK_OK;
 }
 // enqueue "after everything rendered so far" on the exchange stream; the render stream goes on with the next batch and
@@ -1177,6 +1188,11 @@ int vmk_allreduce_framebuffer(vmk_ctx *ctx, void *recv_device) {
 int vmk_allgather_framebuffer(vmk_ctx *ctx, const vmk_tiles *tiles, void *recv_device) {
     if (!ctx) return VMK_ERR_ARG;
     if (!tiles || !tiles->tile_size || (tiles->tile_size & (tiles->tile_size - 1)) || !tiles->world || tiles->rank >= tiles->world || !recv_device || recv_device == (void *) ctx->fb) { ctx->error = "vmk_allgather_framebuffer: bad argument"; return VMK_ERR_ARG; }
+    if (ctx->comm && ((int) tiles->world != ctx->comm_world || (int) tiles->rank != ctx->comm_rank)) {
+        // (the receive buffer and the unpack table are sized from `tiles`, ncclAllGather writes per the communicator: a mismatch is a buffer overrun)
+        ctx->error = "vmk_allgather_framebuffer: vmk_tiles (rank " + std::to_string(tiles->rank) + " of " + std::to_string(tiles->world) + ") disagrees with the communicator (rank " + std::to_string(ctx->comm_rank) + " of " + std::to_string(ctx->comm_world) + ")";
+        return VMK_ERR_ARG;
+    }
     int rc = comm_begin(ctx, "vmk_allgather_framebuffer");
     if (rc != VMK_OK) return rc;
     const uint32_t ts = tiles->tile_size, world = tiles->world, W = ctx->params.width, H = ctx->params.height;
