@@ -252,9 +252,10 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
             if constexpr (ANYHIT) { if (idle && owner >= 0) { if (q == 0) io.store(owner, found, VMK_INVALID, VMK_INVALID, VMK_INVALID, 0.f, 0.f); owner = -1; } }
             else if (idle && owner >= 0) {
                 // ---- retire: the lane that holds the quad's best candidate (min t, then inst, then prim) returns it ----
-                float m = found ? bt : __builtin_inff();
-                m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
-                m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
+                uint32_t mb = found ? f2u(bt) : 0x7f800000u; // (+inf; bit-pattern minimum, see the leaf phase)
+                mb = min(mb, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) mb));
+                mb = min(mb, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) mb));
+                const float m = u2f(mb);
                 const bool c1 = found && bt == m;
                 uint32_t ki = c1 ? binst : 0xffffffffu;
                 ki = min(ki, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) ki));
@@ -388,9 +389,12 @@ VD void traverse_core(const DScene &S, IO &io, WaveScratch *ws, DCounters &cnt, 
                 found = ((uint32_t) (__ballot(found) >> (lane & ~3u)) & 0xfu) != 0u;
                 if (found) cur = kTravDone;
             } else {
-                float m = found ? bt : t_max;
-                m = __builtin_fminf(m, quad_perm_f<kQuadXor1>(m));
-                m = __builtin_fminf(m, quad_perm_f<kQuadXor2>(m));
+                // (quad minimum over the BIT PATTERNS: distances are positive, so unsigned integer order is float order, and v_min_u32
+                // takes its DPP operand directly — a float min would spend a move and two canonicalising max per step on top)
+                uint32_t mb = f2u(found ? bt : t_max);
+                mb = min(mb, (uint32_t) quad_perm_i<kQuadXor1>((int32_t) mb));
+                mb = min(mb, (uint32_t) quad_perm_i<kQuadXor2>((int32_t) mb));
+                const float m = u2f(mb);
                 best_t = m;
                 if (anyh && m < t_max) cur = kTravDone; // (an occlusion query in a mixed pool: some lane of the quad has a hit)
             }
