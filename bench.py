@@ -340,8 +340,9 @@ def main():
                                   "valu_busy_pct": pmc.get("VALUBusy"), "lane_utilization_pct": pmc.get("VALUUtilization"),
                                   "note": "4 cycles = one wave64 instruction issued by one wave alone, 2 = SIMD-32 rate with several waves (guide, constants table); VALUBusy is the hardware's own figure",
                                   "source": f"profiles/{pmc['tag']}_pmc.json"}
-                    rl["limiter"] = "VALU issue (VALUBusy %.0f %%, %.0f %% of the lanes active): HBM sees %.2f of its peak, the touched-bytes rate is served by L2 / Infinity Cache" % (
-                        pmc.get("VALUBusy", float("nan")), pmc.get("VALUUtilization", float("nan")), rl["hbm_counter_frac"])
+                    rl["limiter"] = ("fetch latency and VALU issue in about equal parts (1/T = L/n + c over 1..6 waves per SIMD, DESIGN.md 4.3; 60 %% of wave-cycles in "
+                                     "s_waitcnt, profiles/r03_issue_wait.json); VALUBusy %.0f %%, %.0f %% of the lanes active; HBM sees %.2f of its peak, the touched-bytes "
+                                     "rate is served by L2 / Infinity Cache") % (pmc.get("VALUBusy", float("nan")), pmc.get("VALUUtilization", float("nan")), rl["hbm_counter_frac"])
         if world == 1 and not a.no_cpu_baseline:
             from oracle import oracle_py
             osc = oracle_py.OracleScene(pipe.host_scene)
