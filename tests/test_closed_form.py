@@ -720,3 +720,48 @@ def test_no_ray_falls_through_a_shared_edge_gpu(built, tmp_path):
     _check_point(img, cnt)
     _, ref, co = _render_oracle(path, False, spp=2)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+# ---- 14. thin lens: the circle of confusion of a plane that is out of focus (thin_lens.cpp:34-42) ----
+# The lens sample p_l (uniform on a disk of radius R: square_to_disk) replaces the ray origin, the ray is aimed at the pinhole ray's
+# point on the focal plane z = F.  For a plane perpendicular to the optical axis at distance D that moves the hit point from the
+# pinhole hit X0 to   X = X0 + p_l (1 - D / F):   a uniform disk of radius  r_c = R |1 - D / F|  around X0.  The emissive half-plane of
+# case 8 (x > 0 emits Le) therefore reads   Le * (1/2 + (s sqrt(1 - s^2) + asin s) / pi),   s = clamp(X0.x / r_c, -1, 1)   — the area
+# fraction of the disk beyond the edge — in every pixel, from the scene's numbers alone.
+LENS_R, LENS_F = 0.3, 2.0
+
+
+def _scene_lens(tmp_path):
+    sc = json.load(open(_scene_edge(tmp_path, {"type": "box", "param": {"radius": [0.001, 0.001]}})))
+    sc["camera"]["param"]["lens_radius"] = LENS_R
+    sc["camera"]["param"]["focal_distance"] = LENS_F
+    out = os.path.join(str(tmp_path), "closed_lens.json")
+    json.dump(sc, open(out, "w"))
+    return out
+
+
+def _check_lens(img):
+    rgb = img[..., :3].astype(np.float64)
+    col = rgb.mean(0)[:, 0] / 2.0                                   # Le.r = 2; every row sees the same edge
+    k = 2.0 * np.tan(np.radians(PL_FOV) / 2.0) / PL_HGT             # world units per pixel on the plane (distance D = 1)
+    x0 = -(PL_W / 2.0 - (np.arange(PL_W) + 0.5)) * k                # pinhole hit of the column's centre (image x runs with world x; the edge is x = 0)
+    r_c = LENS_R * abs(1.0 - 1.0 / LENS_F)
+    s = np.clip(x0 / r_c, -1.0, 1.0)
+    want = 0.5 + (s * np.sqrt(1.0 - s * s) + np.arcsin(s)) / np.pi
+    blurred = (np.abs(x0) < r_c).sum()
+    assert blurred >= 6                                             # the circle of confusion spans several columns: the test sees its shape
+    assert np.abs(col - want).max() < 0.02, (np.abs(col - want).max(), col[PL_W // 2 - 5:PL_W // 2 + 5], want[PL_W // 2 - 5:PL_W // 2 + 5])
+    assert (col[x0 < -(r_c + k)] == 0.0).all() and np.allclose(col[x0 > r_c + k], 1.0, atol=1e-6)  # outside the circle: nothing / everything
+
+
+def test_thin_lens_circle_of_confusion_oracle(built, tmp_path):
+    hs, img, cnt = _render_oracle(_scene_lens(tmp_path), False, spp=2048)
+    assert abs(hs.params.lens_radius - LENS_R) < 1e-6 and abs(hs.params.focal_distance - LENS_F) < 1e-6
+    _check_lens(img)
+
+
+@pytest.mark.gpu
+def test_thin_lens_circle_of_confusion_gpu(built, tmp_path):
+    path = _scene_lens(tmp_path)
+    hs, img, cnt = _render_gpu(path, False, spp=2048)
+    _check_lens(img)
