@@ -543,6 +543,34 @@ def test_cbox_prism_agrees_with_the_reference_render(backend):
     assert report["srgb"][3] < 0.15 * ref_size, report["srgb"]                                            # and they are dispersion, not geometry
 
 
+def test_classroom_texture_detail_agrees_with_the_reference_render(backend):
+    """What the textures SHOW, against the reference's own 1024-spp render of classroom (tests/golden/classroom_ref_detail.npz: band-passed
+    luminance of the two notice boards, the blackboard and the lectern — image textures on OBJ meshes).  The lighting cannot be compared
+    (the environment map is stripped; a procedural sky stands in), local texture detail can: normalised cross-correlation 0.83-0.88 on the
+    boards, ~0 for a mirrored or upside-down lookup.  Pins, independently of the twin oracle: OBJ import with flip_uv, uv interpolation,
+    the JPEG decoder's row order, instance transforms and the camera (the regions are fixed pixel boxes of the 1280 x 720 frame)."""
+    from scipy.ndimage import gaussian_filter
+    hs, p, osc, _ = _load(backend, "scenes/classroom/vision_scene.json", 1280, 720)
+    lin = _render_linear(backend, 256)
+    srgb = lambda x: np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(np.maximum(x, 1e-12), 1 / 2.4) - 0.055)
+    lum = srgb(1.0 - np.exp(-lin)) @ np.array([0.2126, 0.7152, 0.0722])
+    band = gaussian_filter(lum, 1.0) - gaussian_filter(lum, 6.0)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "classroom_ref_detail.npz"))
+
+    def ncc(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+    report = {}
+    for name, floor in (("left_board", 0.75), ("right_board", 0.75), ("blackboard", 0.7), ("lectern", 0.5)):
+        y0, y1, x0, x1 = (int(v) for v in z[name + "_box"])
+        mine, ref = band[y0:y1, x0:x1], z[name].astype(np.float64)
+        report[name] = (ncc(mine, ref), ncc(mine[:, ::-1], ref), ncc(mine[::-1], ref))
+    print("classroom texture detail vs the reference's render (ncc as rendered, mirrored, upside down):", {k: [round(x, 3) for x in v] for k, v in report.items()})
+    for name, floor in (("left_board", 0.75), ("right_board", 0.75), ("blackboard", 0.7), ("lectern", 0.5)):
+        as_is, mirrored, upside_down = report[name]
+        assert as_is > floor and mirrored < 0.4 and upside_down < 0.4, (name, report[name])
+
+
 def test_glass_of_water_agrees_with_the_reference_render(backend):
     """Second picture of the reference's own: its 1024-spp render of glass-of-water (tests/golden/glass_of_water_ref.npz: decoded
     with the exposure curve 1 - exp(-x) + sRGB that picture carries, clipped sparkles excluded, tools/make_golden_refimage.py).  The

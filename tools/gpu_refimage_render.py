@@ -16,6 +16,7 @@ JOBS = [  # (name, scene, w, h, options)
     ("cbox_prism_srgb", "scenes/cbox/cbox-prism.json", 1024, 1024, {"spectrum": "srgb"}),
     ("staircase", "scenes/staircase/vision_scene.json", 720, 1280, {}),
     ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 1280, 720, {}),
+    ("classroom", "scenes/classroom/vision_scene.json", 1280, 720, {}),
 ]
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, scene, w, h, kw in JOBS:

@@ -5,6 +5,9 @@
       = res/render_scene/cbox/cbox-prism.json exactly as shipped (glass sphere LASF9, checker back wall, spectrum/hero dimension 4,
       1024x1024; scenes/cbox/cbox-prism.json is that file).  Encoding found by fit on the diffuse walls: ONE ACES tone map
       (exposure 1) + sRGB; gallery/dispersion.png is the same picture through the double tone map of Pipeline::final_picture.
+  res/render_scene/classroom/output-1024spp.png                -> tests/golden/classroom_ref_detail.npz
+      band-passed luminance of the textured regions (notice boards, blackboard, lectern): texture ORIENTATION, not lighting (the scene's
+      environment map is stripped from the checkout).
   res/render_scene/glass-of-water/glass-of-water-1024spp.png   -> tests/golden/glass_of_water_ref.npz
       Encoding: exposure 1 - exp(-x) + sRGB (not saved through final_picture).
 
@@ -67,6 +70,19 @@ if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden", "cbox_prism_ref.npz")
     np.savez_compressed(out, valid=np.packbits(valid), lin=block_sums(lin, valid), fringe=fr.astype(np.float16), shape=np.array(ref.shape[:2]))
     print(out, "valid", valid.mean(), "mean", lin[valid].mean(0))
+    # ---- classroom: texture detail ----
+    # The environment map of this scene is stripped from the checkout, so its LIGHTING cannot be compared — but what the textures show can:
+    # the two notice boards and the blackboard carry image textures on OBJ meshes (flip_uv, uv interpolation, JPEG decode, row order), and
+    # their band-passed luminance (gaussian 1 px minus gaussian 6 px: local detail, indifferent to exposure and to smooth illumination) is
+    # kept for the regions below.  A render whose texture lookups were mirrored or transposed decorrelates completely.
+    ref = np.asarray(Image.open(f"{REF}/classroom/output-1024spp.png").convert("RGB")).astype(np.float64) / 255.0
+    lum = ref @ np.array([0.2126, 0.7152, 0.0722])
+    band = gaussian_filter(lum, 1.0) - gaussian_filter(lum, 6.0)
+    regions = {"left_board": (296, 424, 244, 336), "right_board": (300, 420, 868, 948), "blackboard": (300, 420, 360, 860), "lectern": (390, 500, 352, 504)}
+    out = os.path.join(ROOT, "tests", "golden", "classroom_ref_detail.npz")
+    np.savez_compressed(out, shape=np.array(ref.shape[:2]), **{k: band[y0:y1, x0:x1].astype(np.float16) for k, (y0, y1, x0, x1) in regions.items()},
+                        **{k + "_box": np.array(v) for k, v in regions.items()})
+    print(out, {k: float(np.abs(band[y0:y1, x0:x1]).mean()) for k, (y0, y1, x0, x1) in regions.items()})
     # ---- glass-of-water ----
     ref = np.asarray(Image.open(f"{REF}/glass-of-water/glass-of-water-1024spp.png").convert("RGB")).astype(np.float64) / 255.0
     valid = ~binary_dilation(ref.max(2) > 0.97, iterations=4)
