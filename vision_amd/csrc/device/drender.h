@@ -7,6 +7,7 @@
 namespace vmkd {
 
 constexpr int kBlock = 256;
+__device__ __forceinline__ uint32_t wave_count(bool p) { return (uint32_t) __popcll(__ballot(p)); } // lanes of the wave with p (uniform)
 #ifndef VMK_WAVES_PER_SIMD
 #define VMK_WAVES_PER_SIMD 6 // __launch_bounds__ 2nd argument of the megakernel (register budget = 512 / n per lane).  Measured on classroom
                              // (Mrays/s, 32-spp probe, round 2: by-value lobe routines, no SLP, no traversal tallies): 4: 2710, 5: 2990,
@@ -86,10 +87,11 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
     if (max_depth == 0) return kPathEnd; // `$for(&bounces, 0, max_depth)` never runs (uniform: P is a kernel argument)
     const bool tail = ps.bounces >= max_depth; // the supplement pass (see above)
     Hit hit;
-    if (active) cnt.closest++;
+    cnt.closest += wave_count(active); // (wave-uniform tallies: one scalar add for the wave, no per-lane register — see DCounters)
     bool found = traverse_wave<COUNT, DEEP, false>(S, ps.ray, active, ws, hit, cnt);
     if (dbg && active) { dbg[0] = u2f(hit.inst); dbg[1] = u2f(hit.prim); dbg[2] = hit.bary.x; dbg[3] = hit.bary.y; }
     bool shade = false; // the lane reached a surface with a material: NEE + scattering follow
+    bool tally_hit = false;
     Interaction it;
     LightSample ls;
     Ray shadow_ray = {mk3(0.f), mk3(0.f, 0.f, 1.f), 0.f};
@@ -142,7 +144,7 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
             ps.ray = spawn_ray(it.pos, it.ng, ps.ray.d);
             pass_through = true;
         } else {
-            if (!has_phase && !tail) cnt.hits++;
+            tally_hit = !has_phase && !tail;
             if (it.light_id != VMK_INVALID) { // integrator.cpp:221-231
                 LightEval ev = light_evaluate_hit_wi(S, P, ps.ray.o, it, cnt SWL_A);
                 float weight = MIS_weight(ps.scatter_pdf, ev.pdf);
@@ -157,10 +159,10 @@ __device__ __forceinline__ int path_bounce(const DScene &S, const vmk_render_par
                 ls = light_sample_wi(S, P, it.pos, sampler, cnt SWL_A);
                 shadow_ray = spawn_ray_to(it.pos, it.ng, ls.p_light);
                 shade = true;
-                cnt.shadow++;
             }
         }
     }
+    cnt.hits += wave_count(tally_hit); cnt.shadow += wave_count(shade);
     Hit sh;
     bool occluded = traverse_wave<COUNT, DEEP, true>(S, shadow_ray, shade, ws, sh, cnt); // (the occlusion-query instance of the loop)
     if (!shade) return pass_through ? kPathGoOn : kPathEnd;
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
                 w_lo = min(b, A.n_items); w_hi = (uint32_t) min((unsigned long long) b + A.chunk, (unsigned long long) A.n_items);
                 if ((unsigned long long) b + A.chunk >= A.n_items) exhausted = true;
             }
+            bool started = false;
             if (!has_path) {
                 uint32_t w = w_lo + (uint32_t) __popcll(need_mask & ((1ull << lane) - 1ull));
                 if (w < w_hi) {
@@ -329,11 +332,11 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
 #endif
                         sampler.start(px, py, frame, 1); // path_tracing kernel, integrator.cpp:93
                         path_begin(ps, P);
-                        has_path = true; item = w;
-                        cnt.paths++;
+                        has_path = true; item = w; started = true;
                     }
                 }
             }
+            cnt.paths += wave_count(started);
             w_lo = min(w_lo + (uint32_t) __popcll(need_mask), w_hi);
         }
         if (!__any(has_path) && exhausted && w_lo >= w_hi) break;
@@ -372,12 +375,10 @@ __global__ __launch_bounds__(kBlock, MEDIA ? VMK_MEDIA_WAVES_PER_SIMD : VMK_WAVE
         }
     }
     // ---- counters: one atomic per wave and counter ----
-    uint32_t c[7] = {cnt.closest, cnt.shadow, cnt.nodes, cnt.tris, cnt.paths, cnt.hits, cnt.tex};
+    // (closest, shadow, paths and hits are wave totals already; the traversal tallies and the texture fetches are per lane)
+    uint32_t c[7] = {cnt.closest, cnt.shadow, wave_sum(cnt.nodes), wave_sum(cnt.tris), cnt.paths, cnt.hits, wave_sum(cnt.tex)};
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        uint32_t s = wave_sum(c[i]);
-        if (lane == 0 && s) atomicAdd(A.counters + i, (unsigned long long) s);
-    }
+    for (int i = 0; i < 7; ++i) if (lane == 0 && c[i]) atomicAdd(A.counters + i, (unsigned long long) c[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------

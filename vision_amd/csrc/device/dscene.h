@@ -77,7 +77,8 @@ VD float4 ldg_off(const void *base, uint32_t byte_off) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-struct DCounters { // per-lane tallies, wave-reduced into vmk_counters at kernel end
+struct DCounters { // tallies, reduced into vmk_counters at kernel end: closest / shadow / paths / hits are WAVE totals (updated with one
+                   // scalar add per wave from a ballot, so they live in scalar registers), nodes / tris / tex are per lane
     uint32_t closest, shadow, nodes, tris, paths, hits, tex;
 };
 
