@@ -3,7 +3,9 @@
 import collections, csv, glob, json, os, sys
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/stall"
 out = {}
-for f in sorted(glob.glob(os.path.join(d, "pmc*", "*", "*_counter_collection.csv"))):
+for g in sorted(glob.glob(os.path.join(d, "pmc*"))):
+    # gpurun MERGES into gpurun_out/, so a pass directory can hold files of earlier calls: the newest one is this call's
+    f = max(glob.glob(os.path.join(g, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if "k_render" in r["Kernel_Name"]]
     n = len({r["Dispatch_Id"] for r in rows}) or 1
     agg = collections.defaultdict(float)
