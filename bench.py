@@ -338,11 +338,13 @@ def main():
                                   "ceiling_4cyc_G_per_s": per_simd_clk / 4 / 1e9, "frac_4cyc": valu / t_s / (per_simd_clk / 4),
                                   "ceiling_2cyc_G_per_s": per_simd_clk / 2 / 1e9, "frac_2cyc": valu / t_s / (per_simd_clk / 2),
                                   "valu_busy_pct": pmc.get("VALUBusy"), "lane_utilization_pct": pmc.get("VALUUtilization"),
-                                  "note": "4 cycles = one wave64 instruction issued by one wave alone, 2 = SIMD-32 rate with several waves (guide, constants table); VALUBusy is the hardware's own figure",
+                                  "note": "measured on this chip at 6 waves per SIMD (tools/experiments/valu_rate.hip, profiles/r03_valu_rate.log): v_fma_f32 2.8-3.1 cycles per wave64 instruction per SIMD, "
+                                          "a v_min/v_max/v_add_u32/v_cndmask mix 4.10, quad-permute DPP moves 4.15, v_pk_fma_f32 5.2 - the traversal's mix is the 4-cycle kind; VALUBusy is the hardware's own figure",
                                   "source": f"profiles/{pmc['tag']}_pmc.json"}
-                    rl["limiter"] = ("fetch latency and VALU issue in about equal parts (1/T = L/n + c over 1..6 waves per SIMD, DESIGN.md 4.3; 60 %% of wave-cycles in "
-                                     "s_waitcnt, profiles/r03_issue_wait.json); VALUBusy %.0f %%, %.0f %% of the lanes active; HBM sees %.2f of its peak, the touched-bytes "
-                                     "rate is served by L2 / Infinity Cache") % (pmc.get("VALUBusy", float("nan")), pmc.get("VALUUtilization", float("nan")), rl["hbm_counter_frac"])
+                    rl["limiter"] = ("VALU issue: %.2f of the 4-cycle-per-instruction rate this instruction mix gets (measured ceiling, DESIGN.md 4.3); VALUBusy %.0f %%, "
+                                     "%.0f %% of the lanes active - about 40 %% of the instructions are BVH node steps at 65 %% quad occupancy, 16 %% leaf phases, 44 %% shading "
+                                     "(profiles/r03_occ_probe.log); HBM sees %.2f of its peak, the touched-bytes rate is served by L2 / Infinity Cache"
+                                     ) % (rl["valu"]["frac_4cyc"], pmc.get("VALUBusy", float("nan")), pmc.get("VALUUtilization", float("nan")), rl["hbm_counter_frac"])
         if world == 1 and not a.no_cpu_baseline:
             from oracle import oracle_py
             osc = oracle_py.OracleScene(pipe.host_scene)
