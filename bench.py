@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--no-sibling", action="store_true", help="skip the counting sibling pass (roofline.achieved is then null)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of BASELINE configs c2 / c4 / c5 after the timed region (N = 1, config c3 only)")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal on one GPU: run the per-step C-ABI exchange with a 1-rank communicator")
+    ap.add_argument("--rehearse-dist", action="store_true", help="rehearsal on one GPU under torch.distributed.run --nproc-per-node 1: initialise the RCCL process "
+                    "group although WORLD_SIZE is 1, so that every `if dist:` branch of the N > 1 path runs (with --force-exchange also the C-ABI communicator beside torch's)")
     ap.add_argument("--save", default=None, help="write the final tone-mapped picture (rank 0)")
     a = ap.parse_args()
 
@@ -136,7 +138,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dist = None
-    if world > 1:
+    if world > 1 or a.rehearse_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")  # RCCL on ROCm: rendezvous, barrier and bookkeeping only — the data path's collective is vmk_allreduce_framebuffer

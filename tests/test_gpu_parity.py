@@ -727,3 +727,21 @@ def test_config5_bathroom2_4k_sampled_tiles_and_eight_emulated_ranks(backend):
         paths += backend.counters()["paths"]
     assert (cover == 1).all() and paths == c_full["paths"]
     assert np.array_equal(total.view(np.uint32), full.view(np.uint32))
+
+
+def test_bench_distributed_path_rehearsal_with_one_rank(tmp_path):
+    """bench.py's N > 1 code path on the one GPU a test box has: torch.distributed.run starts ONE rank, --rehearse-dist initialises the RCCL
+    process group anyway (so every `if dist:` branch runs: id broadcast, agreement all-reduce, barriers, max-over-ranks timing) and
+    --force-exchange creates the C-ABI communicator beside torch's and runs vmk_allreduce_framebuffer after every step.  What a second
+    rank would add — another GPU — cannot be rehearsed here; the 2-rank tile arithmetic is covered on the CPU (test_oracle_render.py)."""
+    import json, subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "c2", "--spp-per-step", "8", "--rehearse-dist", "--force-exchange",
+           "--no-cpu-baseline", "--no-other-configs", "--no-replay"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+    assert line["config"]["exchange"].startswith("allreduce behind the C-ABI"), line["config"]["exchange"]
+    assert line["self_check"].startswith("megakernel == unit kernel")
