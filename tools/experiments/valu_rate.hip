@@ -6,10 +6,11 @@
 #define ITERS 8192
 #define REP16(X) X X X X X X X X X X X X X X X X
 template<int KIND>
-__global__ __launch_bounds__(64) void k(float *out, float a, float b) {
+__global__ __launch_bounds__(64) void k(float *out, float a, float b, int nact) {
     float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {r0, r1}, p1 = {r2, r3}, p2 = {r4, r5}, p3 = {r6, r7}, pa = {a, a}, pb = {b, b};
+    if ((int) threadIdx.x < nact)
     for (int i = 0; i < ITERS; ++i) {
         if (KIND == 0) { // v_fma_f32
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -44,18 +45,18 @@ __global__ __launch_bounds__(64) void k(float *out, float a, float b) {
     out[blockIdx.x * 64 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 }
 template<int KIND>
-static void run(const char *name, int waves_per_simd, float *out) {
+static void run(const char *name, int waves_per_simd, float *out, int nact = 64) {
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
     const int simds = pr.multiProcessorCount * 4, blocks = simds * waves_per_simd;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, 1.0000001f, 1e-9f);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, 1.0000001f, 1e-9f, nact);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, 1.0000001f, 1e-9f);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, out, 1.0000001f, 1e-9f, nact);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double instr = (double) blocks * ITERS * 16.0, rate = instr / (ms * 1e-3);
-    printf("%-12s %d waves/SIMD: %7.3f ms, %.3e wave-instructions/s, %.2f cycles per instruction per SIMD at %d MHz (%d SIMDs)\n", name, waves_per_simd, ms, rate,
+    printf("%-12s %2d lanes %d waves/SIMD: %7.3f ms, %.3e wave-instructions/s, %.2f cycles per instruction per SIMD at %d MHz (%d SIMDs)\n", name, nact, waves_per_simd, ms, rate,
            (double) simds * pr.clockRate * 1e3 / rate, pr.clockRate / 1000, simds);
 }
 int main() {
@@ -64,5 +65,8 @@ int main() {
     for (int w : {1, 2, 6}) { run<1>("v_pk_fma_f32", w, out); }
     for (int w : {1, 2, 6}) { run<2>("min/max/add/cndmask", w, out); }
     for (int w : {1, 2, 6}) { run<3>("v_mov_dpp", w, out); }
+    // does the SIMD skip the 16-lane passes of a wave64 instruction whose EXEC bits are all zero?  (lanes >= nact are masked off)
+    for (int n : {48, 32, 16, 4}) { run<2>("min/max/add/cndmask", 6, out, n); }
+    for (int n : {32, 16}) { run<0>("v_fma_f32", 6, out, n); }
     return 0;
 }
