@@ -745,3 +745,78 @@ def test_bench_distributed_path_rehearsal_with_one_rank(tmp_path):
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
     assert line["config"]["exchange"].startswith("allreduce behind the C-ABI"), line["config"]["exchange"]
     assert line["self_check"].startswith("megakernel == unit kernel")
+
+
+def test_coffee_maker_agrees_with_the_reference_test_case_picture(backend):
+    """Third image-level pin against pixels the REFERENCE produced — and the first on substrate (coated plastic) and mirror materials, three
+    quad area lights, a thin-lens camera and twenty OBJ meshes under matrix transforms: res/test_case/coffee/output.png, the expected picture
+    of the reference's own test case (tools/auto_test.py runs the scene; nothing there compares the picture).  One mesh of the scene, the
+    glass carafe, is not in the checkout; the picture's upper three quarters do not show it.
+    Two things had to be found (tools/make_golden_refimage.py): the picture is plain sRGB of the linear accumulation (clipped; 8 % of the
+    pixels are excluded on both sides), and it was taken with fov_y 20 — the class default, the file says 25 — and the look_at direction
+    mirrored in yaw and pitch, i.e. by an older reading of the same file.  Neither was fitted: with exactly those two changes
+    (scenes/coffee/vision_scene_refcam.json) the render aligns with the picture block for block (correlation of log luminance 0.999; 0.89
+    with the file's camera as today's reference and this build read it) and then agrees in ABSOLUTE radiance, no scale: backdrop, orange
+    body (lit and shadowed side), cap within 5 % per channel.  The black base right above the missing carafe is 16 % brighter (documented,
+    bounded); the chrome pipe, a few pixels wide and mirroring the surroundings, within 12 %."""
+    import refimage_util as ru
+    z, valid, refb = ru.load("coffee_ref.npz")
+    shape = (1000, 800)
+    box = lambda x0, x1, y0, y1: ru.block_mask(shape, lambda x, y: (x >= x0) & (x < x1) & (y >= y0) & (y < y1))
+    R = {"backdrop_left": box(20, 150, 100, 400), "backdrop_right": box(650, 780, 100, 400), "backdrop_top": box(100, 700, 10, 90), "backdrop_low": box(20, 140, 800, 990),
+         "body_front": box(420, 560, 250, 640), "body_left": box(260, 330, 250, 560), "cap": box(380, 470, 130, 152), "base": box(300, 520, 690, 740), "pipe": box(160, 186, 520, 740)}
+    upper = np.zeros(refb.shape[:2], bool); upper[:740 // 8] = True
+    def corr(mb):
+        lum = lambda b: np.log(b @ np.array([0.2126, 0.7152, 0.0722]) + 1e-3)
+        a, b = lum(mb)[upper], lum(refb)[upper]
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+    luma = lambda r: float(np.dot(r, [0.2126, 0.7152, 0.0722]))
+    hs, p, osc, _ = _load(backend, "scenes/coffee/vision_scene_refcam.json", 800, 1000, missing_assets="standin")
+    assert "Mesh010.obj" in hs.description and hs.description.count("stand-in") == 1  # the carafe, nothing else
+    mb = ru.block_sums(_render_linear(backend, 512), valid)
+    ratios = ru.region_ratios(mb, refb, R)
+    c = corr(mb)
+    print("coffee maker vs the reference's test-case picture: block correlation %.4f" % c, {a: [round(float(v), 3) for v in b] for a, b in ratios.items()})
+    assert c > 0.995, c
+    for name in ("backdrop_left", "backdrop_right", "backdrop_top", "backdrop_low", "body_front", "body_left", "cap"):
+        assert np.all(np.abs(ratios[name] - 1.0) < 0.05), (name, ratios[name])  # absolute radiance, per channel
+    assert 1.0 < luma(ratios["base"]) < 1.3, ratios["base"]     # lit from below where the carafe is missing
+    assert abs(luma(ratios["pipe"]) - 1.0) < 0.12, ratios["pipe"]
+    # the same comparison through the camera of the file as shipped must FAIL: the pin sees a camera error
+    hs, p, osc, _ = _load(backend, "scenes/coffee/vision_scene.json", 800, 1000, missing_assets="standin")
+    assert corr(ru.block_sums(_render_linear(backend, 64), valid)) < 0.95
+
+
+def test_staircase_agrees_with_the_reference_gallery_picture(backend):
+    """Fourth image-level pin, on the one shipped scene that loads with NO stand-in and is made of textures (wood, wallpaper, parquet on OBJ
+    meshes): gallery/staircase.png.  Like the coffee picture it is plain sRGB of the linear accumulation taken with fov_y 20 and a mirrored
+    pitch (tools/make_golden_refimage.py); unlike it, its yaw had to be FITTED (one parameter), so this pin is the weaker of the two and its
+    limits are wider.  Through that camera the render correlates with the picture block for block (0.998; 0.88 through the file's camera) and
+    carries its ABSOLUTE radiance, no scale fitted: parquet, both wallpapers, the side of the stairs, the panelling and the chair's seat within
+    8 % per channel (measured +3 … +6 %, the blue channel highest — a small systematic excess that is recorded here, not explained), the
+    table top within 15 %.  The lamp (a shade around a light, next to clipped pixels) is reported, not asserted."""
+    import refimage_util as ru
+    z, valid, refb = ru.load("staircase_ref.npz")
+    shape = (1280, 720)
+    box = lambda x0, x1, y0, y1: ru.block_mask(shape, lambda x, y: (x >= x0) & (x < x1) & (y >= y0) & (y < y1))
+    R = {"floor": box(60, 460, 980, 1250), "wallpaper_under_stairs": box(20, 300, 300, 520), "wallpaper_top": box(560, 700, 20, 160), "stair_side": box(560, 700, 480, 900),
+         "panel": box(580, 700, 230, 400), "chair_seat": box(280, 420, 750, 775), "table": box(40, 220, 720, 760), "lamp": box(170, 260, 545, 600)}
+    def corr(mb):
+        lum = lambda b: np.log(b @ np.array([0.2126, 0.7152, 0.0722]) + 1e-3)
+        a, b = lum(mb).ravel(), lum(refb).ravel()
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+    hs, p, osc, _ = _load(backend, "scenes/staircase/vision_scene_refcam.json", 720, 1280)
+    assert "stand-in" not in hs.description
+    mb = ru.block_sums(_render_linear(backend, 256), valid)
+    ratios = ru.region_ratios(mb, refb, R)
+    c = corr(mb)
+    print("staircase vs the reference's gallery picture: block correlation %.4f" % c, {a: [round(float(v), 3) for v in b] for a, b in ratios.items()})
+    assert c > 0.99, c
+    for name in ("floor", "wallpaper_under_stairs", "stair_side", "panel", "chair_seat"):
+        assert np.all(np.abs(ratios[name] - 1.0) < 0.08), (name, ratios[name])
+    for name in ("wallpaper_top", "table"):
+        assert np.all(np.abs(ratios[name] - 1.0) < 0.15), (name, ratios[name])
+    hs, p, osc, _ = _load(backend, "scenes/staircase/vision_scene.json", 720, 1280)
+    assert corr(ru.block_sums(_render_linear(backend, 32), valid)) < 0.95  # the file's own camera: the pin sees the difference
