@@ -18,10 +18,7 @@ JOBS = [  # (name, scene, w, h, options)
     ("glass_of_water", "scenes/glass-of-water/vision_scene.json", 1280, 720, {}),
     ("classroom", "scenes/classroom/vision_scene.json", 1280, 720, {}),
     ("coffee", "scenes/coffee/vision_scene.json", 800, 1000, {"missing_assets": "standin"}),
-    ("staircase_refcam_a", "scenes/staircase/vision_scene_refcam_a.json", 720, 1280, {}),
-    ("staircase_refcam_b", "scenes/staircase/vision_scene_refcam_b.json", 720, 1280, {}),
-    ("staircase_refcam20", "scenes/staircase/vision_scene_refcam20.json", 720, 1280, {}),
-    ("staircase_refcam35", "scenes/staircase/vision_scene_refcam35.json", 720, 1280, {}),
+    ("staircase_refcam", "scenes/staircase/vision_scene_refcam.json", 720, 1280, {}),
     ("coffee_refcam", "scenes/coffee/vision_scene_refcam.json", 800, 1000, {"missing_assets": "standin"}),  # res/test_case/coffee: the glass carafe (Mesh010.obj) is not in the checkout
 ]
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
