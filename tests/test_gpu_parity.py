@@ -749,7 +749,7 @@ def test_bench_distributed_path_rehearsal_with_one_rank(tmp_path):
 
 def test_coffee_maker_agrees_with_the_reference_test_case_picture(backend):
     """Third image-level pin against pixels the REFERENCE produced — and the first on substrate (coated plastic) and mirror materials, three
-    quad area lights, a thin-lens camera and twenty OBJ meshes under matrix transforms: res/test_case/coffee/output.png, the expected picture
+    quad area lights and twenty OBJ meshes under matrix transforms: res/test_case/coffee/output.png, the expected picture
     of the reference's own test case (tools/auto_test.py runs the scene; nothing there compares the picture).  One mesh of the scene, the
     glass carafe, is not in the checkout; the picture's upper three quarters do not show it.
     Two things had to be found (tools/make_golden_refimage.py): the picture is plain sRGB of the linear accumulation (clipped; 8 % of the
